@@ -1,0 +1,336 @@
+"""ctypes binding of libgmpnp.so (include/gmpnp.h) — the only way the package computes anything.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, ``DeviceSolver``
+raises.  Arrays cross the boundary as contiguous fp64 / int32 / int64 numpy buffers in mesh-file
+vertex order (dof = vertex * n_fields + field).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_double, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from .model import CModel, CQuadrature, Model, to_cmodel, to_cquadrature
+from .problem import Problem
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmpnp.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_LINEAR, ERR_NUMERIC = 0, -1, -2, -3, -4, -5
+LINEAR_TWOLEVEL, LINEAR_JACOBI, LINEAR_BLOCK_TRIDIAGONAL = 0, 1, 2
+MAX_HISTORY = 64
+
+EXPORTS = [
+    "gmpnp_version", "gmpnp_last_error", "gmpnp_create", "gmpnp_destroy", "gmpnp_set_model",
+    "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
+    "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
+    "gmpnp_n_aggregates", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
+    "gmpnp_time_kernel", "gmpnp_spmv_profile",
+]
+
+
+class CMesh(ctypes.Structure):
+    _fields_ = [("dim", c_int32), ("n_vertices", c_int32), ("n_cells", c_int32),
+                ("coords", POINTER(c_double)), ("cells", POINTER(c_int32)), ("perm", POINTER(c_int32)),
+                ("n_wall_facets", c_int32), ("wall_facets", POINTER(c_int32)),
+                ("n_exit_facets", c_int32), ("exit_facets", POINTER(c_int32)),
+                ("n_point_vertices", c_int32), ("point_vertices", POINTER(c_int32))]
+
+
+class CNewtonOptions(ctypes.Structure):
+    _fields_ = [("maximum_iterations", c_int32), ("relative_tolerance", c_double),
+                ("absolute_tolerance", c_double), ("relaxation_parameter", c_double),
+                ("linear_solver", c_int32), ("krylov_relative_tolerance", c_double),
+                ("krylov_absolute_tolerance", c_double), ("krylov_maximum_iterations", c_int32)]
+
+
+class CNewtonStats(ctypes.Structure):
+    _fields_ = [("iterations", c_int32), ("converged", c_int32), ("krylov_iterations", c_int32),
+                ("n_residuals", c_int32), ("residuals", c_double * MAX_HISTORY),
+                ("krylov_per_iteration", c_int32 * MAX_HISTORY),
+                ("ms_assemble", c_double), ("ms_setup", c_double), ("ms_krylov", c_double), ("ms_total", c_double)]
+
+
+class CLinearStats(ctypes.Structure):
+    _fields_ = [("iterations", c_int32), ("converged", c_int32), ("residual_norm", c_double),
+                ("rhs_norm", c_double)]
+
+
+class COptions(ctypes.Structure):
+    _fields_ = [("device_id", c_int32), ("n_aggregates", c_int32), ("use_graph", c_int32),
+                ("krylov_batch", c_int32), ("profile_every", c_int32)]
+
+
+class GmpnpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libgmpnp status %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: str = None):
+    """Load libgmpnp.so (built by ``__graft_entry__.build()``).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("HIP backend %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % p)
+    lib = ctypes.CDLL(p)
+    lib.gmpnp_version.restype = ctypes.c_char_p
+    lib.gmpnp_last_error.restype = ctypes.c_char_p
+    lib.gmpnp_create.argtypes = [POINTER(CMesh), POINTER(CModel), POINTER(CQuadrature), POINTER(COptions),
+                                 POINTER(c_void_p)]
+    lib.gmpnp_destroy.argtypes = [c_void_p]
+    lib.gmpnp_destroy.restype = None
+    lib.gmpnp_set_model.argtypes = [c_void_p, POINTER(CModel)]
+    lib.gmpnp_set_dirichlet.argtypes = [c_void_p, c_int64, POINTER(c_int64), POINTER(c_double)]
+    lib.gmpnp_set_state.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_get_state.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_assign_previous.argtypes = [c_void_p]
+    lib.gmpnp_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
+    lib.gmpnp_n_fields.argtypes = [c_void_p]
+    lib.gmpnp_n_fields.restype = c_int32
+    for name in ("gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz"):
+        getattr(lib, name).argtypes = [c_void_p]
+        getattr(lib, name).restype = c_int64
+    lib.gmpnp_n_aggregates.argtypes = [c_void_p]
+    lib.gmpnp_n_aggregates.restype = c_int32
+    lib.gmpnp_assemble.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_get_jacobian_csr.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_double)]
+    lib.gmpnp_spmv.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_linear_solve.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), c_int32, c_double, c_double,
+                                       c_int32, POINTER(CLinearStats)]
+    lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
+    lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(POINTER(c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(POINTER(c_int32))
+
+
+def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -> np.ndarray:
+    """Internal vertex order handed to ``gmpnp_create`` (``perm[internal] = file``).
+
+    Vertices are sorted along the principal axis of the point cloud (for the pore: z), so contiguous
+    ranges are slabs — they become the coarse-space aggregates of the two-level preconditioner and the
+    per-GPU partitions.  Inside windows of ``window`` vertices the order is then stably re-sorted by
+    decreasing node degree, which makes the rows of one SELL slice equally long (padding < 2 %)."""
+    nv = coords.shape[0]
+    X = coords - coords.mean(axis=0)
+    if coords.shape[1] == 1:
+        key = X[:, 0]
+    else:
+        _, vecs = np.linalg.eigh(X.T @ X)
+        axis = vecs[:, -1]
+        axis = axis * np.sign(axis[np.argmax(np.abs(axis))])
+        key = X @ axis
+    order = np.argsort(key, kind="stable")
+    k = cells.shape[1]
+    pairs = np.unique(np.repeat(cells, k, axis=1).ravel().astype(np.int64) * nv + np.tile(cells, (1, k)).ravel())
+    deg = np.bincount((pairs // nv).astype(np.int64), minlength=nv)
+    out = order.copy()
+    for w0 in range(0, nv, window):
+        seg = order[w0:w0 + window]
+        out[w0:w0 + window] = seg[np.argsort(-deg[seg], kind="stable")]
+    return out.astype(np.int32)
+
+
+def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptions:
+    """Translate the reference's ``solver_parameters`` dict (3D:789-798, 1D:357-364) + [3P] DOLFIN
+    defaults.  Direct solvers ('default', 'lu', 'mumps', 'umfpack', 'superlu', 'petsc') map to the
+    "exact-equivalent" two-level BiCGStab at 1e-10 relative residual; 'bicgstab' honours
+    ``preconditioner`` ('jacobi' | anything else -> two-level) and a ``krylov_solver`` sub-dict."""
+    sp = dict(solver_parameters or {})
+    if sp.get("nonlinear_solver", "newton") != "newton":
+        raise RuntimeError("nonlinear_solver %r is not available" % sp.get("nonlinear_solver"))
+    ns = dict(sp.get("newton_solver", {}))
+    o = CNewtonOptions()
+    o.maximum_iterations = int(ns.get("maximum_iterations", 50))
+    o.relative_tolerance = float(ns.get("relative_tolerance", 1e-9))
+    o.absolute_tolerance = float(ns.get("absolute_tolerance", 1e-10))
+    o.relaxation_parameter = float(ns.get("relaxation_parameter", 1.0))
+    lin = ns.get("linear_solver", "default")
+    ks = dict(ns.get("krylov_solver", {}))
+    if lin in ("default", "lu", "mumps", "umfpack", "superlu", "superlu_dist", "petsc"):
+        o.linear_solver = LINEAR_TWOLEVEL
+        o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-10))
+    elif lin == "bicgstab":
+        o.linear_solver = LINEAR_JACOBI if ns.get("preconditioner", "default") == "jacobi" else LINEAR_TWOLEVEL
+        o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-6))
+    else:
+        raise RuntimeError("linear_solver %r is not available in the MI355X backend" % lin)
+    o.krylov_absolute_tolerance = float(ks.get("absolute_tolerance", 0.0))
+    o.krylov_maximum_iterations = int(ks.get("maximum_iterations", 10000))
+    return o
+
+
+class DeviceSolver:
+    """Device-resident GMPNP problem (one handle = one GPU, one HIP stream)."""
+
+    def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, use_graph: bool = True,
+                 krylov_batch: int = 0, profile_every: int = 0, perm: np.ndarray = None, lib=None):
+        self.lib = lib or load_library()
+        self.problem = problem
+        self.nf = problem.nf
+        self.ndof = problem.ndof
+        d = problem.coords.shape[1]
+        self._coords = np.ascontiguousarray(problem.coords, dtype=np.float64)
+        self._cells = np.ascontiguousarray(problem.cells, dtype=np.int32)
+        self.perm = np.ascontiguousarray(
+            slab_permutation(self._coords, self._cells) if perm is None else perm, dtype=np.int32)
+        self._wall = np.ascontiguousarray(problem.wall_facets, dtype=np.int32).reshape(-1, 3)
+        self._exit = np.ascontiguousarray(problem.exit_facets, dtype=np.int32).reshape(-1, 3)
+        self._pts = np.ascontiguousarray(problem.point_vertices, dtype=np.int32)
+        m = CMesh()
+        m.dim, m.n_vertices, m.n_cells = d, self._coords.shape[0], self._cells.shape[0]
+        m.coords, m.cells, m.perm = _dptr(self._coords), _iptr(self._cells), _iptr(self.perm)
+        m.n_wall_facets, m.wall_facets = len(self._wall), _iptr(self._wall)
+        m.n_exit_facets, m.exit_facets = len(self._exit), _iptr(self._exit)
+        m.n_point_vertices, m.point_vertices = len(self._pts), _iptr(self._pts)
+        cm, cq = to_cmodel(problem.model), to_cquadrature(problem.quad)
+        opts = COptions(device_id, n_aggregates, 0 if use_graph else 2, krylov_batch, profile_every)
+        h = c_void_p()
+        self._h = None
+        self._check(self.lib.gmpnp_create(byref(m), byref(cm), byref(cq), byref(opts), byref(h)))
+        self._h = h
+        if len(problem.bc_dofs):
+            self.set_dirichlet(problem.bc_dofs, problem.bc_vals)
+
+    # ------------------------------------------------------------------------------------------
+    def _check(self, code):
+        if code != OK:
+            raise GmpnpError(code, self.lib.gmpnp_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gmpnp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def n_blocks(self):
+        return int(self.lib.gmpnp_n_blocks(self._h))
+
+    @property
+    def jacobian_nnz(self):
+        return int(self.lib.gmpnp_jacobian_nnz(self._h))
+
+    @property
+    def n_aggregates(self):
+        return int(self.lib.gmpnp_n_aggregates(self._h))
+
+    def set_model(self, model: Model):
+        cm = to_cmodel(model)
+        self._check(self.lib.gmpnp_set_model(self._h, byref(cm)))
+
+    def set_dirichlet(self, dofs, vals):
+        dofs = np.ascontiguousarray(dofs, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        if dofs.shape != vals.shape:
+            raise ValueError("dofs and values differ in length")
+        self._check(self.lib.gmpnp_set_dirichlet(self._h, len(dofs), dofs.ctypes.data_as(POINTER(c_int64)), _dptr(vals)))
+
+    def set_state(self, u=None, un=None):
+        pu = pn = None
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64).ravel()
+            assert u.size == self.ndof
+            pu = _dptr(u)
+        if un is not None:
+            un = np.ascontiguousarray(un, dtype=np.float64).ravel()
+            assert un.size == self.ndof
+            pn = _dptr(un)
+        self._check(self.lib.gmpnp_set_state(self._h, pu, pn))
+
+    def get_state(self, previous=False):
+        out = np.empty(self.ndof)
+        if previous:
+            self._check(self.lib.gmpnp_get_state(self._h, None, _dptr(out)))
+        else:
+            self._check(self.lib.gmpnp_get_state(self._h, _dptr(out), None))
+        return out
+
+    def assign_previous(self):
+        self._check(self.lib.gmpnp_assign_previous(self._h))
+
+    def assemble(self, want_jacobian=True):
+        """Returns (b, ||b||_2); the Jacobian stays on the device (``jacobian_csr`` exports it)."""
+        F = np.empty(self.ndof)
+        norm = c_double()
+        self._check(self.lib.gmpnp_assemble(self._h, int(bool(want_jacobian)), _dptr(F), byref(norm)))
+        return F, norm.value
+
+    def jacobian_csr(self):
+        import scipy.sparse as sp
+        nnz = self.jacobian_nnz
+        indptr = np.empty(self.ndof + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz)
+        self._check(self.lib.gmpnp_get_jacobian_csr(self._h, _iptr(indptr), _iptr(indices), _dptr(data)))
+        return sp.csr_matrix((data, indices, indptr), shape=(self.ndof, self.ndof))
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.ndof)
+        self._check(self.lib.gmpnp_spmv(self._h, _dptr(x), _dptr(y)))
+        return y
+
+    def linear_solve(self, b, linear_solver=LINEAR_TWOLEVEL, rtol=1e-10, atol=0.0, max_iterations=10000):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty(self.ndof)
+        st = CLinearStats()
+        code = self.lib.gmpnp_linear_solve(self._h, _dptr(b), _dptr(x), linear_solver, rtol, atol, max_iterations, byref(st))
+        self._check(code)
+        return x, {"iterations": st.iterations, "converged": bool(st.converged), "residual_norm": st.residual_norm,
+                   "rhs_norm": st.rhs_norm}
+
+    def newton_solve(self, options: CNewtonOptions, error_on_nonconvergence=True):
+        """``solve(F == 0, u, bcs, solver_parameters)`` on the device state.  Raises RuntimeError on
+        non-convergence like [3P] DOLFIN (error_on_nonconvergence=True)."""
+        st = CNewtonStats()
+        code = self.lib.gmpnp_newton_solve(self._h, byref(options), byref(st))
+        stats = {"iterations": st.iterations, "converged": bool(st.converged),
+                 "krylov_iterations": st.krylov_iterations,
+                 "residuals": [st.residuals[i] for i in range(st.n_residuals)],
+                 "krylov_per_iteration": [st.krylov_per_iteration[i] for i in range(min(st.iterations, MAX_HISTORY))],
+                 "ms_assemble": st.ms_assemble, "ms_setup": st.ms_setup, "ms_krylov": st.ms_krylov,
+                 "ms_total": st.ms_total}
+        if code == ERR_NOT_CONVERGED and not error_on_nonconvergence:
+            return stats
+        self._check(code)
+        return stats
+
+    def time_kernel(self, kernel: int, launches: int = 50) -> float:
+        us = c_double()
+        self._check(self.lib.gmpnp_time_kernel(self._h, kernel, launches, byref(us)))
+        return us.value
+
+    def spmv_profile(self):
+        n, mean, launched = c_int64(), c_double(), c_int64()
+        self._check(self.lib.gmpnp_spmv_profile(self._h, byref(n), byref(mean), byref(launched)))
+        return {"sampled": n.value, "mean_us": mean.value, "launched": launched.value}

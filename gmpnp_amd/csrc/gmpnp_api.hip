@@ -1,0 +1,758 @@
+// C ABI of libgmpnp.so (include/gmpnp.h): handle, host drivers of assembly, preconditioner setup,
+// BiCGStab and the damped Newton loop ([3P] dolfin::NewtonSolver semantics).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "gmpnp_kernels.h"
+
+using namespace gmpnp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(GMPNP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));              \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count, bool zero = true) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess && zero) e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    hipError_t e = alloc(v.size(), v.empty());
+    if (e == hipSuccess && !v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct gmpnp_solver {
+  Topology t;
+  gmpnp_model_t model{};
+  gmpnp_quadrature_t quad{};
+  gmpnp_options_t opts{};
+  int dim = 0, nf = 0, nn = 0, ndof = 0, nb = 0, ncoarse = 0;
+  int n_resblocks = 0;
+  hipStream_t stream = nullptr;
+  Ctx c{};
+  // boundary facets kept on the host (internal vertex ids) to rebuild flux tables when the model changes
+  std::vector<int32_t> wall_f, exit_f, point_v;
+  // device storage
+  DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
+  DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, Dinv, AP, Ac, AciT;
+  DevBuf<double> kr, krhat, kp, kv, ks, kt, ky, kq, pc_part, yc, part_rr, part_a, part_b, part_f, tmpx;
+  DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
+      sell_cols, wl_slice, wl_kpos, diag_kpos, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
+  DevBuf<int64_t> rob_addr, slice_off;
+  DevBuf<uint8_t> bcflag, sell_aggslot;
+  DevBuf<KrylovScalars> scal;
+  std::vector<uint8_t> h_bcflag; std::vector<double> h_bcval;
+  // pinned read-back areas
+  KrylovScalars* h_scal = nullptr; double* h_part = nullptr; int32_t* h_status = nullptr;
+  // Krylov graph (one per preconditioner mode)
+  hipGraphExec_t graph[2] = {nullptr, nullptr};
+  int graph_iters = 4;
+  int last_krylov_iters = 0;
+  bool jacobian_valid = false, precond_valid = false;
+  int precond_mode = -1;
+  // SpMV event sampling (eager mode)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
+  int64_t spmv_launched = 0, spmv_sampled = 0; double spmv_us_sum = 0.0;
+  hipEvent_t ev_phase[6] = {};
+
+  ~gmpnp_solver() {
+    for (auto& g : graph) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : ev_phase) if (e) (void)hipEventDestroy(e);
+    if (h_scal) (void)hipHostFree(h_scal);
+    if (h_part) (void)hipHostFree(h_part);
+    if (h_status) (void)hipHostFree(h_status);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// ---- dispatch on (dim, n_fields) ---------------------------------------------------------------
+#define GMPNP_DISPATCH(s, CALL)                                   \
+  do {                                                            \
+    if ((s)->dim == 3 && (s)->nf == 9) { constexpr int DIM = 3, NF = 9; CALL; } \
+    else if ((s)->dim == 1 && (s)->nf == 7) { constexpr int DIM = 1, NF = 7; CALL; } \
+    else return fail(GMPNP_ERR_INVALID, "unsupported (dim, n_fields)"); \
+  } while (0)
+
+int grid_for(int n, int block) { return (n + block - 1) / block; }
+
+// Facet / point integrals that do not depend on u, and the Robin mass entries (SURVEY App. D "facets").
+int rebuild_boundary(gmpnp_solver* s) {
+  const Topology& t = s->t;
+  const int nf = s->nf, ns = nf - 1;
+  std::vector<double> bnd((size_t)s->ndof, 0.0);
+  struct Ent { int row, col; double v; };
+  std::vector<Ent> ents;
+  auto area = [&](const int32_t* f) {
+    const double* a = &t.coords[(size_t)f[0] * 3]; const double* b = &t.coords[(size_t)f[1] * 3];
+    const double* c = &t.coords[(size_t)f[2] * 3];
+    const double ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+    const double vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+    const double cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+    return 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+  };
+  if (s->dim == 3) {
+    for (size_t k = 0; k + 2 < s->wall_f.size(); k += 3) {
+      const int32_t* f = &s->wall_f[k]; const double ar = area(f);
+      for (int i = 0; i < ns; ++i)
+        if (s->model.wall_flux[i] != 0.0)
+          for (int a = 0; a < 3; ++a) bnd[(size_t)f[a] * nf + i] += s->model.wall_flux[i] * ar / 3.0;
+    }
+    for (size_t k = 0; k + 2 < s->exit_f.size(); k += 3) {
+      const int32_t* f = &s->exit_f[k]; const double ar = area(f);
+      for (int i = 0; i < ns; ++i) {
+        const double kap = s->model.exit_kappa[i];
+        if (kap == 0.0) continue;
+        for (int a = 0; a < 3; ++a) {
+          bnd[(size_t)f[a] * nf + i] += -kap * ar / 3.0;
+          for (int b = 0; b < 3; ++b) ents.push_back({f[a] * nf + i, f[b] * nf + i, kap * ar * (a == b ? 2.0 : 1.0) / 12.0});
+        }
+      }
+    }
+  }
+  for (int v : s->point_v)
+    for (int i = 0; i < ns; ++i) bnd[(size_t)v * nf + i] += s->model.point_flux[i];
+  // merge duplicates (stable order of first appearance => deterministic)
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
+  std::vector<int32_t> rrow, rcol, rptr((size_t)s->ndof + 1, 0); std::vector<double> rval; std::vector<int64_t> raddr;
+  for (size_t k = 0; k < ents.size();) {
+    size_t j = k; double v = 0.0;
+    while (j < ents.size() && ents[j].row == ents[k].row && ents[j].col == ents[k].col) v += ents[j++].v;
+    const int row = ents[k].row, col = ents[k].col;
+    const int I = row / nf, i = row % nf, J = col / nf, jf = col % nf;
+    const int32_t* b = t.cols.data() + t.rowptr[I]; const int32_t* e = t.cols.data() + t.rowptr[I + 1];
+    const int kpos = (int)(std::lower_bound(b, e, J) - b);
+    const int sl = I / t.S, il = I - sl * t.S;
+    rrow.push_back(row); rcol.push_back(col); rval.push_back(v);
+    raddr.push_back(t.slice_off[sl] + (int64_t)(kpos * nf + jf) * kWave + il * nf + i);
+    rptr[row + 1]++;
+    k = j;
+  }
+  for (int r = 0; r < s->ndof; ++r) rptr[r + 1] += rptr[r];
+  HIP_TRY(s->bndF.upload(bnd)); HIP_TRY(s->robF_ptr.upload(rptr)); HIP_TRY(s->rob_col.upload(rcol));
+  HIP_TRY(s->rob_row.upload(rrow)); HIP_TRY(s->rob_val.upload(rval)); HIP_TRY(s->rob_addr.upload(raddr));
+  s->c.bndF = s->bndF.p; s->c.robF_ptr = s->robF_ptr.p; s->c.rob_col = s->rob_col.p; s->c.rob_row = s->rob_row.p;
+  s->c.rob_val = s->rob_val.p; s->c.rob_addr = s->rob_addr.p; s->c.n_robin = (int)rval.size();
+  return GMPNP_OK;
+}
+
+int check_model(const gmpnp_model_t* m, int dim) {
+  if (!m) return fail(GMPNP_ERR_INVALID, "model is NULL");
+  if (m->dim != dim) return fail(GMPNP_ERR_INVALID, "model.dim != mesh.dim");
+  if (m->n_species < 1 || m->n_species > GMPNP_MAX_SPECIES) return fail(GMPNP_ERR_INVALID, "model.n_species out of range");
+  if (m->n_bilinear < 0 || m->n_bilinear > GMPNP_MAX_BILINEAR) return fail(GMPNP_ERR_INVALID, "model.n_bilinear out of range");
+  for (int t = 0; t < m->n_bilinear; ++t)
+    if (m->bil_j[t] < 0 || m->bil_j[t] >= m->n_species || m->bil_k[t] < 0 || m->bil_k[t] >= m->n_species)
+      return fail(GMPNP_ERR_INVALID, "model.bil_j/bil_k out of range");
+  if (!(m->inv_dt == m->inv_dt)) return fail(GMPNP_ERR_INVALID, "model.inv_dt is NaN");
+  return GMPNP_OK;
+}
+
+// ---- device passes --------------------------------------------------------------------------
+template <int DIM, int NF>
+int launch_element(gmpnp_solver* s, bool want_j) {
+  const int g = grid_for(s->t.nc, 64);
+  if (want_j) hipLaunchKernelGGL((k_element<DIM, NF, true>), dim3(g), dim3(64), 0, s->stream, s->c);
+  else hipLaunchKernelGGL((k_element<DIM, NF, false>), dim3(g), dim3(64), 0, s->stream, s->c);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+template <int DIM, int NF>
+int launch_res_gather(gmpnp_solver* s) {
+  hipLaunchKernelGGL((k_res_gather<DIM, NF>), dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, s->c);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+template <int DIM, int NF>
+int launch_jac_gather(gmpnp_solver* s) {
+  const int g = grid_for(s->c.n_work * kWave, kVecBlock);
+  hipLaunchKernelGGL((k_jac_gather<DIM, NF>), dim3(g), dim3(kVecBlock), 0, s->stream, s->c);
+  if (s->c.n_robin > 0) hipLaunchKernelGGL(k_robin_add, dim3(grid_for(s->c.n_robin, 256)), dim3(256), 0, s->stream, s->c);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+// residual at the current u: returns ||b||_2 and the device status flags
+template <int DIM, int NF>
+int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
+  int rc = launch_element<DIM, NF>(s, want_j); if (rc) return rc;
+  rc = launch_res_gather<DIM, NF>(s); if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double acc = 0.0;
+  for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
+  *norm = std::sqrt(acc);
+  *flags = *s->h_status;
+  return GMPNP_OK;
+}
+
+template <int DIM, int NF>
+int setup_preconditioner(gmpnp_solver* s, int mode) {
+  hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 64)), dim3(64), 0, s->stream, s->c);
+  if (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) {
+    hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
+    hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg), dim3(kVecBlock), 0, s->stream, s->c);
+    const int n = s->ncoarse;
+    const size_t lds = (size_t)(n * n + 2 * n + 16) * sizeof(double) + (size_t)(16 + n) * sizeof(int);
+    hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(1024), lds, s->stream, s->c);
+  }
+  HIP_TRY(hipGetLastError());
+  s->precond_valid = true; s->precond_mode = mode;
+  return GMPNP_OK;
+}
+
+template <int NF, int MODE>
+int launch_spmv(gmpnp_solver* s, const double* x, double* out, bool sample) {
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (sample) {
+    if (s->ev_used == s->ev_pool.size()) {
+      hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); s->ev_pool.push_back({a, b});
+    }
+    ev = &s->ev_pool[s->ev_used++];
+    HIP_TRY(hipEventRecord(ev->first, s->stream));
+  }
+  hipLaunchKernelGGL((k_spmv<NF, MODE>), dim3(s->t.nslices), dim3(kVecBlock), 0, s->stream, s->c, x, out);
+  if (ev) HIP_TRY(hipEventRecord(ev->second, s->stream));
+  s->spmv_launched++;
+  return GMPNP_OK;
+}
+
+int drain_spmv_events(gmpnp_solver* s) {
+  for (size_t i = 0; i < s->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second));
+    s->spmv_us_sum += 1000.0 * ms; s->spmv_sampled++;
+  }
+  s->ev_used = 0;
+  return GMPNP_OK;
+}
+
+template <int NF>
+int enqueue_iteration(gmpnp_solver* s, int use_coarse, bool allow_sampling) {
+  const int every = s->opts.profile_every;
+  hipLaunchKernelGGL((k_vec1<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  int rc = launch_spmv<NF, 1>(s, s->kq.p, s->kv.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_vec2<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  rc = launch_spmv<NF, 2>(s, s->kq.p, s->kt.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
+  return rc;
+}
+
+// Solve J dx = rhs (rhs already in c.kr on the device, ||rhs|| = bnorm) with right-preconditioned BiCGStab;
+// leaves y in c.ky; the caller applies M^{-1}.
+template <int NF>
+int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st) {
+  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  const int n = s->ndof;
+  // rhat = r ; y = 0
+  hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr, s->kr.p, n);
+  HIP_TRY(hipMemsetAsync(s->ky.p, 0, n * sizeof(double), s->stream));
+  KrylovScalars init{};
+  init.rho = bnorm * bnorm; init.rho_next = init.rho; init.alpha = 1.0;
+  init.tol = std::max(rtol * bnorm, atol); init.rr = init.rho; init.iters = 0; init.max_iters = maxit; init.done = 0;
+  if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
+  *s->h_scal = init;
+  HIP_TRY(hipMemcpyAsync(s->scal.p, s->h_scal, sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));  // h_scal is reused for read-back below
+  const bool use_graph = (s->opts.use_graph != 2) && s->opts.profile_every == 0;
+  const int B = s->graph_iters;
+  if (use_graph && !s->graph[use_coarse]) {
+    hipGraph_t g;
+    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    int rc = GMPNP_OK;
+    for (int it = 0; it < B && rc == GMPNP_OK; ++it) rc = enqueue_iteration<NF>(s, use_coarse, false);
+    hipError_t e = hipStreamEndCapture(s->stream, &g);
+    if (rc) return rc;
+    HIP_TRY(e);
+    HIP_TRY(hipGraphInstantiate(&s->graph[use_coarse], g, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(g));
+  }
+  int launched = 0;
+  int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, s->last_krylov_iters - 2);
+  KrylovScalars res = init;
+  while (!res.done) {
+    int want = (launched == 0) ? first : B;
+    want = ((want + B - 1) / B) * B;
+    for (int k = 0; k < want; k += B) {
+      if (use_graph) HIP_TRY(hipGraphLaunch(s->graph[use_coarse], s->stream));
+      else for (int it = 0; it < B; ++it) { int rc = enqueue_iteration<NF>(s, use_coarse, true); if (rc) return rc; }
+    }
+    launched += want;
+    HIP_TRY(hipMemcpyAsync(s->h_scal, s->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    res = *s->h_scal;
+    int rc = drain_spmv_events(s); if (rc) return rc;
+    if (launched > maxit + 2 * B && !res.done) break;  // defensive: the device test ends the loop at max_iters
+  }
+  s->last_krylov_iters = res.iters;
+  if (st) { st->iterations = res.iters; st->converged = (res.done == 1); st->residual_norm = std::sqrt(res.rr); st->rhs_norm = bnorm; }
+  if (res.done != 1) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "BiCGStab stopped without convergence (code %d) after %d iterations, ||r|| = %.3e, ||b|| = %.3e",
+             res.done, res.iters, std::sqrt(res.rr), bnorm);
+    return fail(GMPNP_ERR_LINEAR, buf);
+  }
+  return GMPNP_OK;
+}
+
+// x = M^{-1} y applied into dst: dst = scale_dst*dst + scale_x*x
+template <int NF>
+int apply_minv(gmpnp_solver* s, int mode, double* dst, double scale_dst, double scale_x) {
+  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  HIP_TRY(hipMemsetAsync(&s->scal.p->done, 0, sizeof(int32_t), s->stream));  // k_coarse honours the flag
+  hipLaunchKernelGGL((k_vec_final<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_apply<NF>), dim3(grid_for(s->ndof, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c, dst, scale_dst, scale_x);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+std::string status_message(int flags) {
+  std::string m;
+  if (flags & 1) m += "1 - sum_j a_j u_j <= 0 at a quadrature point; ";
+  if (flags & 2) m += "singular diagonal node block; ";
+  if (flags & 4) m += "singular coarse operator; ";
+  return m;
+}
+
+template <int DIM, int NF>
+int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_t& st) {
+  const double t0 = now_ms();
+  HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+  double r = 0.0; int flags = 0;
+  double ta = now_ms();
+  int rc = residual<DIM, NF>(s, false, &r, &flags); if (rc) return rc;
+  st.ms_assemble += now_ms() - ta;
+  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  const double r0 = r;
+  st.residuals[0] = r; st.n_residuals = 1;
+  auto conv = [&](double res) {
+    if (!(res == res)) return false;
+    const double rel = res / r0;  // 0/0 = NaN compares false, as in DOLFIN
+    return rel < o.relative_tolerance || res < o.absolute_tolerance;
+  };
+  bool done = conv(r);
+  if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual is NaN before the first Newton iteration");
+  while (!done && st.iterations < o.maximum_iterations) {
+    ta = now_ms();
+    rc = launch_element<DIM, NF>(s, true); if (rc) return rc;
+    rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc;
+    s->jacobian_valid = true;
+    HIP_TRY(hipEventRecord(s->ev_phase[0], s->stream));
+    rc = setup_preconditioner<DIM, NF>(s, o.linear_solver); if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev_phase[1], s->stream));
+    // rhs = b (current residual vector F)
+    HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    const double tk = now_ms();
+    gmpnp_linear_stats_t ls{};
+    rc = krylov<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
+                    o.krylov_maximum_iterations, &ls);
+    if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
+    st.krylov_iterations += ls.iterations;
+    if (rc) {
+      HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (*s->h_status) g_err += " [" + status_message(*s->h_status) + "]";
+      return rc;
+    }
+    // x <- x - omega dx
+    rc = apply_minv<NF>(s, o.linear_solver, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
+    const double tk1 = now_ms();
+    st.iterations++;
+    rc = residual<DIM, NF>(s, false, &r, &flags); if (rc) return rc;
+    const double te = now_ms();
+    float ms_setup = 0.f;
+    (void)hipEventElapsedTime(&ms_setup, s->ev_phase[0], s->ev_phase[1]);
+    st.ms_setup += ms_setup;
+    st.ms_krylov += (tk1 - tk);
+    st.ms_assemble += (tk - ta) - ms_setup + (te - tk1);
+    if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+    if (flags & 6) return fail(GMPNP_ERR_LINEAR, status_message(flags));
+    if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
+    if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
+    done = conv(r);
+  }
+  st.converged = done ? 1 : 0;
+  st.ms_total = now_ms() - t0;
+  if (!done) return fail(GMPNP_ERR_NOT_CONVERGED, "Newton solver did not converge because maximum number of iterations reached");
+  return GMPNP_OK;
+}
+
+void to_internal(const gmpnp_solver* s, const double* src, std::vector<double>& dst) {
+  const int nf = s->nf, nv = s->t.nv;
+  dst.resize((size_t)nv * nf);
+  for (int i = 0; i < nv; ++i) std::memcpy(&dst[(size_t)i * nf], &src[(size_t)s->t.perm[i] * nf], nf * sizeof(double));
+}
+
+void to_file(const gmpnp_solver* s, const std::vector<double>& src, double* dst) {
+  const int nf = s->nf, nv = s->t.nv;
+  for (int i = 0; i < nv; ++i) std::memcpy(&dst[(size_t)s->t.perm[i] * nf], &src[(size_t)i * nf], nf * sizeof(double));
+}
+
+int upload_vec(gmpnp_solver* s, const double* file_order, double* dev) {
+  std::vector<double> tmp; to_internal(s, file_order, tmp);
+  HIP_TRY(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return GMPNP_OK;
+}
+
+int download_vec(gmpnp_solver* s, const double* dev, double* file_order) {
+  std::vector<double> tmp((size_t)s->ndof);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  to_file(s, tmp, file_order);
+  return GMPNP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* gmpnp_version(void) { return "gmpnp-mi355x 0.1 (gfx950)"; }
+const char* gmpnp_last_error(void) { return g_err.c_str(); }
+
+int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                 const gmpnp_options_t* opts, gmpnp_solver** out) {
+  if (!mesh || !quad || !out) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  int rc = check_model(model, mesh->dim); if (rc) return rc;
+  const int nf = model->n_species + 1;
+  if (!((mesh->dim == 3 && nf == 9) || (mesh->dim == 1 && nf == 7)))
+    return fail(GMPNP_ERR_INVALID, "supported spaces: 3D with 8 species + potential, 1D with 6 species + potential");
+  if (quad->nq_f < 1 || quad->nq_f > GMPNP_MAX_QUAD || quad->nq_j < 1 || quad->nq_j > GMPNP_MAX_QUAD)
+    return fail(GMPNP_ERR_INVALID, "quadrature size out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(GMPNP_ERR_HIP, "no HIP device visible: libgmpnp.so has no CPU fallback");
+  std::unique_ptr<gmpnp_solver> s(new gmpnp_solver);
+  if (opts) s->opts = *opts;
+  if (s->opts.device_id < 0 || s->opts.device_id >= ndev) return fail(GMPNP_ERR_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  std::string err = build_topology(*mesh, nf, s->opts.n_aggregates, s->t);
+  if (!err.empty()) return fail(GMPNP_ERR_INVALID, err);
+  Topology& t = s->t;
+  s->dim = mesh->dim; s->nf = nf; s->nn = mesh->dim + 1; s->ndof = t.nv * nf; s->nb = (int)t.cols.size();
+  s->ncoarse = t.nagg * nf;
+  s->model = *model; s->quad = *quad;
+  auto conv_facets = [&](int n, const int32_t* f, std::vector<int32_t>& dst, const char* what) -> int {
+    if (n < 0 || (n > 0 && !f)) return fail(GMPNP_ERR_INVALID, std::string("bad ") + what);
+    dst.resize((size_t)n * 3);
+    for (size_t k = 0; k < dst.size(); ++k) {
+      if (f[k] < 0 || f[k] >= t.nv) return fail(GMPNP_ERR_INVALID, std::string(what) + " references a vertex outside the mesh");
+      dst[k] = t.iperm[f[k]];
+    }
+    return GMPNP_OK;
+  };
+  if (mesh->dim == 3) {
+    rc = conv_facets(mesh->n_wall_facets, mesh->wall_facets, s->wall_f, "wall_facets"); if (rc) return rc;
+    rc = conv_facets(mesh->n_exit_facets, mesh->exit_facets, s->exit_f, "exit_facets"); if (rc) return rc;
+  }
+  for (int k = 0; k < mesh->n_point_vertices; ++k) {
+    const int v = mesh->point_vertices[k];
+    if (v < 0 || v >= t.nv) return fail(GMPNP_ERR_INVALID, "point_vertices references a vertex outside the mesh");
+    s->point_v.push_back(t.iperm[v]);
+  }
+  HIP_TRY(hipStreamCreate(&s->stream));
+  for (auto& e : s->ev_phase) HIP_TRY(hipEventCreate(&e));
+  if (s->opts.krylov_batch < 0 || s->opts.profile_every < 0) return fail(GMPNP_ERR_INVALID, "negative option");
+
+  const int nv = t.nv, nc = t.nc, nn = s->nn, ndof = s->ndof;
+  const int ej_stride = (mesh->dim == 3) ? Lay<3, 9>::EJ_STRIDE : Lay<1, 7>::EJ_STRIDE;
+  s->n_resblocks = grid_for(ndof, kVecBlock);
+  const int n_vecwg = (int)t.vw_node0.size();
+  std::vector<gmpnp_model_t> mv(1, s->model); std::vector<gmpnp_quadrature_t> qv(1, s->quad);
+  HIP_TRY(s->d_model.upload(mv)); HIP_TRY(s->d_quad.upload(qv));
+  HIP_TRY(s->coords.upload(t.coords)); HIP_TRY(s->cells.upload(t.cells));
+  HIP_TRY(s->u.alloc(ndof)); HIP_TRY(s->un.alloc(ndof)); HIP_TRY(s->F.alloc(ndof));
+  s->h_bcflag.assign(ndof, 0); s->h_bcval.assign(ndof, 0.0);
+  HIP_TRY(s->bcflag.upload(s->h_bcflag)); HIP_TRY(s->bcval.upload(s->h_bcval));
+  HIP_TRY(s->EF.alloc((size_t)nc * nn * nf)); HIP_TRY(s->EJ.alloc((size_t)nc * ej_stride));
+  HIP_TRY(s->n2e_ptr.upload(t.n2e_ptr)); HIP_TRY(s->n2e.upload(t.n2e));
+  HIP_TRY(s->rowptr.upload(t.rowptr)); HIP_TRY(s->cols.upload(t.cols));
+  HIP_TRY(s->cptr.upload(t.cptr)); HIP_TRY(s->contrib.upload(t.contrib));
+  HIP_TRY(s->vals.alloc((size_t)t.slice_off[t.nslices]));
+  HIP_TRY(s->slice_off.upload(t.slice_off)); HIP_TRY(s->slice_colbase.upload(t.slice_colbase));
+  HIP_TRY(s->sell_cols.upload(t.sell_cols)); HIP_TRY(s->sell_aggslot.upload(t.sell_aggslot));
+  HIP_TRY(s->wl_slice.upload(t.wl_slice)); HIP_TRY(s->wl_kpos.upload(t.wl_kpos));
+  HIP_TRY(s->diag_kpos.upload(t.diag_kpos));
+  HIP_TRY(s->Dinv.alloc((size_t)nv * nf * nf));
+  HIP_TRY(s->agg.upload(t.agg)); HIP_TRY(s->agg_start.upload(t.agg_start)); HIP_TRY(s->row_aggs.upload(t.row_aggs));
+  HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
+  HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->AciT.alloc((size_t)s->ncoarse * s->ncoarse));
+  HIP_TRY(s->vw_node0.upload(t.vw_node0)); HIP_TRY(s->vw_node1.upload(t.vw_node1)); HIP_TRY(s->agg_vw_ptr.upload(t.agg_vw_ptr));
+  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp, &s->kv, &s->ks, &s->kt, &s->ky, &s->kq, &s->tmpx}) HIP_TRY(b->alloc(ndof));
+  HIP_TRY(s->pc_part.alloc((size_t)n_vecwg * nf)); HIP_TRY(s->yc.alloc(kMaxCoarse));
+  HIP_TRY(s->part_rr.alloc(n_vecwg)); HIP_TRY(s->part_a.alloc(t.nslices)); HIP_TRY(s->part_b.alloc((size_t)4 * t.nslices));
+  HIP_TRY(s->part_f.alloc(s->n_resblocks));
+  HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
+  HIP_TRY(hipHostMalloc((void**)&s->h_scal, sizeof(KrylovScalars)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_part, std::max(s->n_resblocks, 1) * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
+
+  Ctx& c = s->c;
+  c.nv = nv; c.nc = nc; c.ndof = ndof; c.nb = s->nb; c.nslices = t.nslices; c.n_work = (int)t.wl_slice.size();
+  c.nagg = t.nagg; c.ncoarse = s->ncoarse; c.n_vecwg = n_vecwg; c.ncp = nc; c.n_robin = 0;
+  c.model = s->d_model.p; c.quad = s->d_quad.p; c.coords = s->coords.p; c.cells = s->cells.p;
+  c.u = s->u.p; c.un = s->un.p; c.F = s->F.p; c.bcflag = s->bcflag.p; c.bcval = s->bcval.p;
+  c.EF = s->EF.p; c.EJ = s->EJ.p; c.n2e_ptr = s->n2e_ptr.p; c.n2e = s->n2e.p;
+  c.rowptr = s->rowptr.p; c.cols = s->cols.p; c.cptr = s->cptr.p; c.contrib = s->contrib.p;
+  c.vals = s->vals.p; c.slice_off = s->slice_off.p; c.slice_colbase = s->slice_colbase.p;
+  c.sell_cols = s->sell_cols.p; c.sell_aggslot = s->sell_aggslot.p; c.wl_slice = s->wl_slice.p; c.wl_kpos = s->wl_kpos.p;
+  c.diag_kpos = s->diag_kpos.p; c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
+  c.AP = s->AP.p; c.Ac = s->Ac.p; c.AciT = s->AciT.p;
+  c.vw_node0 = s->vw_node0.p; c.vw_node1 = s->vw_node1.p; c.agg_vw_ptr = s->agg_vw_ptr.p;
+  c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp = s->kp.p; c.kv = s->kv.p; c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kq = s->kq.p;
+  c.pc_part = s->pc_part.p; c.yc = s->yc.p; c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
+  c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
+  rc = rebuild_boundary(s.get()); if (rc) return rc;
+  // the coarse inverse keeps its whole matrix in LDS: opt in to > 64 KiB of dynamic LDS
+  const int n = s->ncoarse;
+  const size_t lds = (size_t)(n * n + 2 * n + 16) * sizeof(double) + (size_t)(16 + n) * sizeof(int);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = s.release();
+  return GMPNP_OK;
+}
+
+void gmpnp_destroy(gmpnp_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->opts.device_id);
+  (void)hipDeviceSynchronize();
+  delete s;
+}
+
+int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  int rc = check_model(model, s->dim); if (rc) return rc;
+  if (model->n_species + 1 != s->nf) return fail(GMPNP_ERR_INVALID, "n_species cannot change after create");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->model = *model;
+  HIP_TRY(hipMemcpy(s->d_model.p, &s->model, sizeof(gmpnp_model_t), hipMemcpyHostToDevice));
+  s->jacobian_valid = false;
+  return rebuild_boundary(s);
+}
+
+int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values) {
+  if (!s || n < 0 || (n > 0 && (!dofs || !values))) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  std::fill(s->h_bcflag.begin(), s->h_bcflag.end(), 0);
+  std::fill(s->h_bcval.begin(), s->h_bcval.end(), 0.0);
+  for (int64_t k = 0; k < n; ++k) {
+    const int64_t d = dofs[k];
+    if (d < 0 || d >= s->ndof) return fail(GMPNP_ERR_INVALID, "Dirichlet dof out of range");
+    const int r = s->t.iperm[d / s->nf] * s->nf + (int)(d % s->nf);
+    s->h_bcflag[r] = 1; s->h_bcval[r] = values[k];
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(s->bcflag.p, s->h_bcflag.data(), s->ndof, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->bcval.p, s->h_bcval.data(), s->ndof * sizeof(double), hipMemcpyHostToDevice));
+  s->jacobian_valid = false;
+  return GMPNP_OK;
+}
+
+int gmpnp_set_state(gmpnp_solver* s, const double* u, const double* u_n) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (u) { int rc = upload_vec(s, u, s->u.p); if (rc) return rc; }
+  if (u_n) { int rc = upload_vec(s, u_n, s->un.p); if (rc) return rc; }
+  s->jacobian_valid = false;
+  return GMPNP_OK;
+}
+
+int gmpnp_get_state(gmpnp_solver* s, double* u_out, double* u_n_out) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  if (u_out) { int rc = download_vec(s, s->u.p, u_out); if (rc) return rc; }
+  if (u_n_out) { int rc = download_vec(s, s->un.p, u_n_out); if (rc) return rc; }
+  return GMPNP_OK;
+}
+
+int gmpnp_assign_previous(gmpnp_solver* s) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipMemcpyAsync(s->un.p, s->u.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GMPNP_OK;
+}
+
+int gmpnp_newton_solve(gmpnp_solver* s, const gmpnp_newton_options_t* o, gmpnp_newton_stats_t* stats) {
+  if (!s || !o) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (o->maximum_iterations < 0 || o->krylov_maximum_iterations < 1) return fail(GMPNP_ERR_INVALID, "bad iteration limits");
+  if (o->linear_solver != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && o->linear_solver != GMPNP_LINEAR_BICGSTAB_JACOBI)
+    return fail(GMPNP_ERR_INVALID, "linear_solver not available in this build");
+  gmpnp_newton_stats_t local{};
+  gmpnp_newton_stats_t& st = stats ? *stats : local;
+  st = gmpnp_newton_stats_t{};
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  int rc;
+  GMPNP_DISPATCH(s, rc = (newton<DIM, NF>(s, *o, st)));
+  return rc;
+}
+
+int32_t gmpnp_n_fields(const gmpnp_solver* s) { return s ? s->nf : 0; }
+int64_t gmpnp_n_dofs(const gmpnp_solver* s) { return s ? s->ndof : 0; }
+int64_t gmpnp_n_blocks(const gmpnp_solver* s) { return s ? s->nb : 0; }
+int64_t gmpnp_jacobian_nnz(const gmpnp_solver* s) { return s ? (int64_t)s->nb * s->nf * s->nf : 0; }
+int32_t gmpnp_n_aggregates(const gmpnp_solver* s) { return s ? s->t.nagg : 0; }
+
+int gmpnp_assemble(gmpnp_solver* s, int32_t want_jacobian, double* F_out, double* norm_out) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+  double r = 0.0; int flags = 0; int rc;
+  GMPNP_DISPATCH(s, rc = (residual<DIM, NF>(s, want_jacobian != 0, &r, &flags)));
+  if (rc) return rc;
+  if (want_jacobian) {
+    GMPNP_DISPATCH(s, rc = (launch_jac_gather<DIM, NF>(s)));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->jacobian_valid = true; s->precond_valid = false;
+  }
+  if (norm_out) *norm_out = r;
+  if (F_out) { rc = download_vec(s, s->F.p, F_out); if (rc) return rc; }
+  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  return GMPNP_OK;
+}
+
+int gmpnp_get_jacobian_csr(gmpnp_solver* s, int32_t* indptr, int32_t* indices, double* data) {
+  if (!s || !indptr || !indices || !data) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  const Topology& t = s->t; const int nf = s->nf;
+  std::vector<double> v((size_t)t.slice_off[t.nslices]);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(v.data(), s->vals.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int64_t pos = 0; indptr[0] = 0;
+  std::vector<std::pair<int, int>> order;  // (file column node, kpos)
+  for (int vf = 0; vf < t.nv; ++vf) {
+    const int I = t.iperm[vf], sl = I / t.S, il = I - sl * t.S;
+    order.clear();
+    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) order.push_back({t.perm[t.cols[k]], k - t.rowptr[I]});
+    std::sort(order.begin(), order.end());
+    for (int i = 0; i < nf; ++i) {
+      for (auto& pr : order)
+        for (int j = 0; j < nf; ++j) {
+          indices[pos] = pr.first * nf + j;
+          data[pos] = v[(size_t)t.slice_off[sl] + (size_t)(pr.second * nf + j) * kWave + il * nf + i];
+          ++pos;
+        }
+      indptr[(size_t)vf * nf + i + 1] = (int32_t)pos;
+    }
+  }
+  return GMPNP_OK;
+}
+
+int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y) {
+  if (!s || !x || !y) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  int rc = upload_vec(s, x, s->tmpx.p); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(s->yc.p, 0, kMaxCoarse * sizeof(double), s->stream));
+  GMPNP_DISPATCH(s, rc = (launch_spmv<NF, 0>(s, s->tmpx.p, s->kt.p, false)));
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return download_vec(s, s->kt.p, y);
+}
+
+int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode, double rtol, double atol,
+                       int32_t maxit, gmpnp_linear_stats_t* stats) {
+  if (!s || !b || !x) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
+    return fail(GMPNP_ERR_INVALID, "linear_solver not available in this build");
+  if (maxit < 1) return fail(GMPNP_ERR_INVALID, "max_iterations < 1");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+  int rc = upload_vec(s, b, s->kr.p); if (rc) return rc;
+  double bn = 0.0;
+  for (int64_t i = 0; i < s->ndof; ++i) bn += b[i] * b[i];
+  bn = std::sqrt(bn);
+  GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
+  if (rc) return rc;
+  gmpnp_linear_stats_t ls{};
+  GMPNP_DISPATCH(s, rc = (krylov<NF>(s, mode, bn, rtol, atol, maxit, &ls)));
+  if (stats) *stats = ls;
+  HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
+  if (rc) return rc;
+  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->tmpx.p, 0.0, 1.0)));
+  if (rc) return rc;
+  return download_vec(s, s->tmpx.p, x);
+}
+
+int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {
+  if (!s || !avg_us || launches < 1) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  if ((kernel == 0 || kernel == 2) && !s->jacobian_valid && kernel == 0)
+    return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+  int rc = GMPNP_OK;
+  if (kernel == 0) HIP_TRY(hipMemsetAsync(s->yc.p, 0, kMaxCoarse * sizeof(double), s->stream));
+  auto one = [&]() -> int {
+    int r = GMPNP_OK;
+    switch (kernel) {
+      case 0: GMPNP_DISPATCH(s, r = (launch_spmv<NF, 0>(s, s->kq.p, s->kt.p, false))); break;
+      case 1: GMPNP_DISPATCH(s, r = (launch_element<DIM, NF>(s, true))); break;
+      case 2: GMPNP_DISPATCH(s, r = (launch_jac_gather<DIM, NF>(s))); break;
+      case 3: GMPNP_DISPATCH(s, r = (launch_res_gather<DIM, NF>(s))); break;
+      default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
+    }
+    return r;
+  };
+  rc = one(); if (rc) return rc;  // warm
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipEventRecord(a, s->stream));
+  for (int i = 0; i < launches && rc == GMPNP_OK; ++i) rc = one();
+  HIP_TRY(hipEventRecord(b, s->stream));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  if (rc) return rc;
+  *avg_us = 1000.0 * ms / launches;
+  if (kernel == 1 || kernel == 2) s->jacobian_valid = (kernel == 2) ? s->jacobian_valid : s->jacobian_valid;
+  return GMPNP_OK;
+}
+
+int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  if (n_sampled) *n_sampled = s->spmv_sampled;
+  if (mean_us) *mean_us = s->spmv_sampled ? s->spmv_us_sum / s->spmv_sampled : 0.0;
+  if (n_launched) *n_launched = s->spmv_launched;
+  s->spmv_sampled = 0; s->spmv_us_sum = 0.0; s->spmv_launched = 0;
+  return GMPNP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,753 @@
+// HIP kernels of the GMPNP hot path for gfx950 (wave64, fp64 VALU; no MFMA: there is no dense contraction).
+//
+//   k_element      per-element P1 residual + the few scalars the exact Jacobian is built from     (a1-a4)
+//   k_res_gather   race-free node gather of the residual, Dirichlet rows b = x - g, ||b||^2      (a5, a6)
+//   k_jac_gather   race-free gather of the node-block Jacobian straight into SELL storage,
+//                  identity Dirichlet rows                                                        (a5, a6)
+//   k_spmv         SELL block SpMV with the coarse prolongation folded into the x gather          (a7)
+//   k_vec1/k_vec2  fused BiCGStab vector updates + block-Jacobi apply + coarse restriction        (a7)
+//   k_coarse       coarse GEMV with the LDS-inverted Galerkin operator                            (a7)
+//
+// Reference mathematics: 3D/MPNP_CO2ER_pore.py:505-769, 1D/MPNP_CO2ER_EDL.py:383-595.
+#pragma once
+#include "gmpnp_internal.h"
+
+namespace gmpnp {
+
+template <int DIM, int NF>
+struct Lay {
+  static constexpr int NS = NF - 1;
+  static constexpr int NN = DIM + 1;
+  static constexpr int S = kWave / NF;  // block rows per SELL slice
+  // element-intermediate record (doubles)
+  static constexpr int O_VOL = 0;
+  static constexpr int O_GG = 1;                 // [NN][NN] grad phi_a . grad phi_b
+  static constexpr int O_GP = O_GG + NN * NN;    // [NN] grad p . grad phi_a
+  static constexpr int O_GG_A = O_GP + NN;       // [NN] G . grad phi_a
+  static constexpr int O_UBAR = O_GG_A + NN;     // [NS]
+  static constexpr int O_EPS = O_UBAR + NS;      // eps(ubar)
+  static constexpr int O_IJ = O_EPS + 1;         // [NS] int u_i beta   (J rule)
+  static constexpr int O_B = O_IJ + NS;          // [NN] int beta phi_b
+  static constexpr int O_C = O_B + NN;           // [NS][NN] int u_i beta^2 phi_b
+  static constexpr int EJ_STRIDE = O_C + NS * NN;
+  static constexpr int EF_STRIDE = NN * NF;
+  static constexpr double MDEN = 1.0 / ((DIM + 1) * (DIM + 2));  // M_ab = |K| (1+delta_ab) MDEN
+  static constexpr double KAPPA = (DIM == 3) ? 1.0 / 120.0 : 1.0 / 24.0;  // d!/(d+3)!
+};
+
+// ---------------------------------------------------------------------------------------------
+// deterministic workgroup reductions (256 threads = 4 waves)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int K>
+__device__ inline void block_sum(double (&v)[K], double* lds /* [4*K] */) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[w * K + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+}
+
+// Sum K partial arrays (each n long, array k at part + k*stride) in a fixed order; every thread gets the totals.
+template <int K>
+__device__ inline void sum_partials(const double* __restrict__ part, int n, int stride, double (&out)[K], double* lds) {
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int i = threadIdx.x; i < n; i += kVecBlock)
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += part[(size_t)k * stride + i];
+  block_sum<K>(v, lds);
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = v[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Element kernel: one lane per cell.
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NF, bool WANT_J>
+__global__ __launch_bounds__(64) void k_element(const Ctx c) {
+  using L = Lay<DIM, NF>;
+  constexpr int NS = L::NS, NN = L::NN;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= c.nc) return;
+  const gmpnp_model_t& m = *c.model;
+  const gmpnp_quadrature_t& qd = *c.quad;
+
+  int nd[NN];
+  double X[NN][DIM], U[NN][NF];
+#pragma unroll
+  for (int a = 0; a < NN; ++a) {
+    nd[a] = c.cells[e * NN + a];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) X[a][d] = c.coords[(size_t)nd[a] * DIM + d];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) U[a][f] = c.u[(size_t)nd[a] * NF + f];
+  }
+  // geometry: |K| and the constant gradients of the P1 basis
+  double g[NN][DIM], vol;
+  if constexpr (DIM == 1) {
+    const double h = X[1][0] - X[0][0];
+    g[0][0] = -1.0 / h; g[1][0] = 1.0 / h; vol = fabs(h);
+  } else {
+    double T[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) T[r][d] = X[r + 1][d] - X[0][d];
+    const double c00 = T[1][1] * T[2][2] - T[1][2] * T[2][1];
+    const double c01 = T[1][2] * T[2][0] - T[1][0] * T[2][2];
+    const double c02 = T[1][0] * T[2][1] - T[1][1] * T[2][0];
+    const double det = T[0][0] * c00 + T[0][1] * c01 + T[0][2] * c02;
+    const double id = 1.0 / det;
+    // columns of T^{-1} are grad phi_1..3
+    g[1][0] = c00 * id; g[1][1] = c01 * id; g[1][2] = c02 * id;
+    g[2][0] = (T[0][2] * T[2][1] - T[0][1] * T[2][2]) * id;
+    g[2][1] = (T[0][0] * T[2][2] - T[0][2] * T[2][0]) * id;
+    g[2][2] = (T[0][1] * T[2][0] - T[0][0] * T[2][1]) * id;
+    g[3][0] = (T[0][1] * T[1][2] - T[0][2] * T[1][1]) * id;
+    g[3][1] = (T[0][2] * T[1][0] - T[0][0] * T[1][2]) * id;
+    g[3][2] = (T[0][0] * T[1][1] - T[0][1] * T[1][0]) * id;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[0][d] = -(g[1][d] + g[2][d] + g[3][d]);
+    vol = fabs(det) * (1.0 / 6.0);
+  }
+  double gg[NN][NN];
+#pragma unroll
+  for (int a = 0; a < NN; ++a)
+#pragma unroll
+    for (int b = 0; b < NN; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) s += g[a][d] * g[b][d];
+      gg[a][b] = s;
+    }
+  double gradp[DIM], G[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    double sp = 0.0, sg = 0.0;
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+      sp += U[a][NS] * g[a][d];
+      double au = 0.0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) au += m.a[j] * U[a][j];
+      sg += au * g[a][d];
+    }
+    gradp[d] = sp; G[d] = sg;
+  }
+  double gp[NN], Gg[NN];
+#pragma unroll
+  for (int a = 0; a < NN; ++a) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { s1 += gradp[d] * g[a][d]; s2 += G[d] * g[a][d]; }
+    gp[a] = s1; Gg[a] = s2;
+  }
+  double usum[NS], ubar[NS], epsbar = m.eps0;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < NN; ++a) s += U[a][j];
+    usum[j] = s; ubar[j] = s * (1.0 / NN); epsbar += m.epsc[j] * ubar[j];
+  }
+  // steric moments
+  double If[NS], Ij[NS], Bq[NN], Cq[NS][NN];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) { If[j] = 0.0; Ij[j] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NN; ++b) Cq[j][b] = 0.0; }
+#pragma unroll
+  for (int b = 0; b < NN; ++b) Bq[b] = 0.0;
+  bool bad = false;
+  if (m.steric) {
+    for (int q = 0; q < qd.nq_f; ++q) {
+      double uq[NS], S = 0.0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < NN; ++b) s += qd.lam_f[q][b] * U[b][j];
+        uq[j] = s; S += m.a[j] * s;
+      }
+      bad |= !(1.0 - S > 0.0);
+      const double wb = qd.w_f[q] * vol / (1.0 - S);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) If[j] += wb * uq[j];
+    }
+    if constexpr (WANT_J) {
+      for (int q = 0; q < qd.nq_j; ++q) {
+        double uq[NS], S = 0.0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int b = 0; b < NN; ++b) s += qd.lam_j[q][b] * U[b][j];
+          uq[j] = s; S += m.a[j] * s;
+        }
+        bad |= !(1.0 - S > 0.0);
+        const double beta = 1.0 / (1.0 - S);
+        const double wb = qd.w_j[q] * vol * beta;
+#pragma unroll
+        for (int b = 0; b < NN; ++b) Bq[b] += wb * qd.lam_j[q][b];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          Ij[j] += wb * uq[j];
+          const double wbb = wb * beta * uq[j];
+#pragma unroll
+          for (int b = 0; b < NN; ++b) Cq[j][b] += wbb * qd.lam_j[q][b];
+        }
+      }
+    }
+  }
+  if (bad) atomicOr(c.status, 1);
+
+  // ---- element residual ------------------------------------------------------------------------
+  double* ef = c.EF + (size_t)e * L::EF_STRIDE;
+  // bilinear monomials int u_x u_y phi_a = |K| kappa (XY + x_a Y + X y_a + D + 2 x_a y_a)
+  double mono[GMPNP_MAX_BILINEAR][NN];
+  for (int t = 0; t < m.n_bilinear; ++t) {
+    const int bj = m.bil_j[t], bk = m.bil_k[t];
+    double xs[NN], ys[NN], Xs = 0.0, Ys = 0.0, D = 0.0;
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+      double xv = 0.0, yv = 0.0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) { xv = (j == bj) ? U[a][j] : xv; yv = (j == bk) ? U[a][j] : yv; }
+      xs[a] = xv; ys[a] = yv; Xs += xv; Ys += yv; D += xv * yv;
+    }
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+      mono[t][a] = vol * L::KAPPA * (Xs * Ys + xs[a] * Ys + Xs * ys[a] + D + 2.0 * xs[a] * ys[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < NN; ++a) {
+    double fp = -epsbar * vol * gp[a];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      // M-weighted nodal sums: sum_b M_ab w_b = |K| MDEN (sum_b w_b + w_a)
+      double du_sum = 0.0;
+#pragma unroll
+      for (int b = 0; b < NN; ++b) du_sum += U[b][i] - c.un[(size_t)nd[b] * NF + i];
+      const double du_a = U[a][i] - c.un[(size_t)nd[a] * NF + i];
+      double f = m.inv_dt * vol * L::MDEN * (du_sum + du_a);
+      double ku = 0.0;
+#pragma unroll
+      for (int b = 0; b < NN; ++b) ku += gg[a][b] * U[b][i];
+      f += vol * ku;
+      f += m.z[i] * vol * ubar[i] * gp[a];
+      f += m.rc0[i] * vol * (1.0 / NN);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) f += m.rc1[i][j] * (vol * L::MDEN * (usum[j] + U[a][j]));
+      for (int t = 0; t < m.n_bilinear; ++t) f += m.rc2[i][t] * mono[t][a];
+      f += If[i] * Gg[a];
+      ef[a * NF + i] = f;
+      fp += m.qzb[i] * (vol * L::MDEN * (usum[i] + U[a][i]));
+    }
+    ef[a * NF + NS] = fp;
+  }
+  if constexpr (WANT_J) {
+    double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
+    ej[L::O_VOL] = vol;
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+#pragma unroll
+      for (int b = 0; b < NN; ++b) ej[L::O_GG + a * NN + b] = gg[a][b];
+      ej[L::O_GP + a] = gp[a]; ej[L::O_GG_A + a] = Gg[a]; ej[L::O_B + a] = Bq[a];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      ej[L::O_UBAR + j] = ubar[j]; ej[L::O_IJ + j] = Ij[j];
+#pragma unroll
+      for (int b = 0; b < NN; ++b) ej[L::O_C + j * NN + b] = Cq[j][b];
+    }
+    ej[L::O_EPS] = epsbar;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Residual gather: one lane per dof; b = sum of incident element rows (+ boundary terms), Dirichlet
+// rows b = x - g ([3P] DirichletBC.apply(b, x)); per-workgroup partial of ||b||^2.
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NF>
+__global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
+  using L = Lay<DIM, NF>;
+  __shared__ double lds[4];
+  const int r = blockIdx.x * kVecBlock + threadIdx.x;
+  double val = 0.0;
+  if (r < c.ndof) {
+    if (c.bcflag[r]) {
+      val = c.u[r] - c.bcval[r];
+    } else {
+      const int I = r / NF, i = r - I * NF;
+      double s = c.bndF[r];
+      for (int k = c.n2e_ptr[I]; k < c.n2e_ptr[I + 1]; ++k) {
+        const int pk = c.n2e[k];
+        const int e = pk / L::NN, a = pk - e * L::NN;
+        s += c.EF[(size_t)e * L::EF_STRIDE + a * NF + i];
+      }
+      for (int k = c.robF_ptr[r]; k < c.robF_ptr[r + 1]; ++k) s += c.rob_val[k] * c.u[c.rob_col[k]];
+      val = s;
+    }
+    c.F[r] = val;
+  }
+  double v[1] = {val * val};
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) c.part_f[blockIdx.x] = v[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobian gather: one wave per (slice, kpos); lane = (block row in slice, scalar row i) computes the
+// NF entries of its row of block (I, cols[kpos]) by summing the element contributions in element
+// order and stores them at stride 64 doubles (each store instruction writes 63 contiguous doubles).
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int NF>
+__global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
+  using L = Lay<DIM, NF>;
+  constexpr int NS = L::NS, NN = L::NN, S = L::S;
+  const int wave = (blockIdx.x * kVecBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= c.n_work) return;
+  const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
+  const int Iloc = lane / NF, i = lane - Iloc * NF;
+  if (Iloc >= S) return;
+  const int I = s * S + Iloc;
+  if (I >= c.nv) return;
+  const int r0 = c.rowptr[I];
+  if (kpos >= c.rowptr[I + 1] - r0) return;  // padding stays zero (set at create)
+  const int k = r0 + kpos, J = c.cols[k];
+  double* out = c.vals + c.slice_off[s] + (size_t)kpos * NF * kWave + lane;
+  if (c.bcflag[I * NF + i]) {  // [3P] DirichletBC.apply(A): identity row
+#pragma unroll
+    for (int j = 0; j < NF; ++j) out[j * kWave] = (J == I && j == i) ? 1.0 : 0.0;
+    return;
+  }
+  const gmpnp_model_t& m = *c.model;
+  const bool isp = (i == NS);
+  const int is = isp ? 0 : i;
+  const double zi = m.z[is], inv_dt = m.inv_dt;
+  double rc1i[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) rc1i[j] = m.rc1[is][j];
+  double acc[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) acc[j] = 0.0;
+
+  for (int q = c.cptr[k]; q < c.cptr[k + 1]; ++q) {
+    const int pk = c.contrib[q];
+    const int e = pk >> 4, a = (pk >> 2) & 3, b = pk & 3;
+    const double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
+    const double vol = ej[L::O_VOL], ggab = ej[L::O_GG + a * NN + b], gpa = ej[L::O_GP + a];
+    const double Mab = vol * L::MDEN * (a == b ? 2.0 : 1.0), Kab = vol * ggab;
+    if (!isp) {
+      const double Gga = ej[L::O_GG_A + a];
+      const double ster = Gga * ej[L::O_C + is * NN + b] + ej[L::O_IJ + is] * ggab;
+      const double dg = inv_dt * Mab + Kab + zi * vol * (1.0 / NN) * gpa + Gga * ej[L::O_B + b];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) acc[j] += m.a[j] * ster + rc1i[j] * Mab + (j == is ? dg : 0.0);
+      for (int t = 0; t < m.n_bilinear; ++t) {
+        const double c2 = m.rc2[is][t];
+        if (c2 != 0.0) {
+          const int bj = m.bil_j[t], bk = m.bil_k[t];
+          const int na = c.cells[e * NN + a], nb_ = c.cells[e * NN + b];
+          const double xa = c.u[(size_t)na * NF + bj], xb = c.u[(size_t)nb_ * NF + bj];
+          const double ya = c.u[(size_t)na * NF + bk], yb = c.u[(size_t)nb_ * NF + bk];
+          const double Xs = NN * ej[L::O_UBAR + bj], Ys = NN * ej[L::O_UBAR + bk];
+          const double w = c2 * vol * L::KAPPA;
+          const double dj = w * (Ys + ya + yb + (a == b ? Ys + 2.0 * ya : 0.0));  // d/d u_{bj,b}
+          const double dk = w * (Xs + xa + xb + (a == b ? Xs + 2.0 * xa : 0.0));  // d/d u_{bk,b}
+#pragma unroll
+          for (int j = 0; j < NS; ++j) acc[j] += (j == bj ? dj : 0.0) + (j == bk ? dk : 0.0);
+        }
+      }
+      acc[NS] += zi * ej[L::O_UBAR + is] * Kab;
+    } else {
+      const double kpa = vol * gpa * (1.0 / NN);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) acc[j] += -m.epsc[j] * kpa + m.qzb[j] * Mab;
+      acc[NS] += -ej[L::O_EPS] * Kab;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NF; ++j) out[j * kWave] = acc[j];
+}
+
+// Robin (exit) mass entries, one lane per pre-merged entry (unique addresses: no atomics).
+__global__ void k_robin_add(const Ctx c) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= c.n_robin) return;
+  if (c.bcflag[c.rob_row[t]]) return;
+  c.vals[c.rob_addr[t]] += c.rob_val[t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Node-block Jacobi: invert the NF x NF diagonal blocks (Gauss-Jordan, partial pivoting, LDS-resident).
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(64) void k_block_inverse(const Ctx c) {
+  constexpr int S = kWave / NF;
+  __shared__ double A[NF * NF][64];
+  const int I = blockIdx.x * 64 + threadIdx.x, t = threadIdx.x;
+  if (I >= c.nv) return;
+  const int s = I / S, Iloc = I - s * S;
+  const double* base = c.vals + c.slice_off[s] + (size_t)c.diag_kpos[I] * NF * kWave + Iloc * NF;
+  for (int i = 0; i < NF; ++i)
+    for (int j = 0; j < NF; ++j) A[i * NF + j][t] = base[(size_t)j * kWave + i];
+  int piv[NF];
+  bool sing = false;
+  for (int k = 0; k < NF; ++k) {
+    int p = k; double best = fabs(A[k * NF + k][t]);
+    for (int r = k + 1; r < NF; ++r) { const double v = fabs(A[r * NF + k][t]); if (v > best) { best = v; p = r; } }
+    piv[k] = p;
+    if (!(best > 0.0)) { sing = true; break; }
+    if (p != k)
+      for (int j = 0; j < NF; ++j) { const double tmp = A[k * NF + j][t]; A[k * NF + j][t] = A[p * NF + j][t]; A[p * NF + j][t] = tmp; }
+    const double ip = 1.0 / A[k * NF + k][t];
+    A[k * NF + k][t] = 1.0;
+    for (int j = 0; j < NF; ++j) A[k * NF + j][t] *= ip;
+    for (int r = 0; r < NF; ++r) {
+      if (r == k) continue;
+      const double f = A[r * NF + k][t];
+      A[r * NF + k][t] = 0.0;
+      for (int j = 0; j < NF; ++j) A[r * NF + j][t] -= f * A[k * NF + j][t];
+    }
+  }
+  if (sing) { atomicOr(c.status, 2); return; }
+  for (int k = NF - 1; k >= 0; --k)
+    if (piv[k] != k)
+      for (int r = 0; r < NF; ++r) { const double tmp = A[r * NF + k][t]; A[r * NF + k][t] = A[r * NF + piv[k]][t]; A[r * NF + piv[k]][t] = tmp; }
+  double* o = c.Dinv + (size_t)I * NF * NF;
+  for (int q = 0; q < NF * NF; ++q) o[q] = A[q][t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coarse operator Ac = P^T A P in two deterministic stages.
+//   stage 1 (k_coarse_rows): AP[r][slot][j] = sum over the row's blocks whose column node lies in aggregate slot
+//   stage 2 (k_coarse_sum) : Ac[g*NF+i][h*NF+j] = sum over nodes I in g of AP[(I,i)][slot(h)][j]
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(64) void k_coarse_rows(const Ctx c) {
+  constexpr int S = kWave / NF;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int Iloc = lane / NF, i = lane - Iloc * NF;
+  if (Iloc >= S) return;
+  const int I = s * S + Iloc;
+  if (I >= c.nv) return;
+  double acc[kMaxRowAggs][NF];
+#pragma unroll
+  for (int q = 0; q < kMaxRowAggs; ++q)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[q][j] = 0.0;
+  const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
+  const double* base = c.vals + c.slice_off[s] + lane;
+  for (int kp = 0; kp < mx; ++kp) {
+    const int slot = c.sell_aggslot[(size_t)(cb + kp) * kSlicePad + Iloc];
+    if (slot == 255) continue;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const double v = base[(size_t)(kp * NF + j) * kWave];
+#pragma unroll
+      for (int q = 0; q < kMaxRowAggs; ++q) acc[q][j] += (q == slot) ? v : 0.0;
+    }
+  }
+  double* o = c.AP + (size_t)(I * NF + i) * kMaxRowAggs * NF;
+#pragma unroll
+  for (int q = 0; q < kMaxRowAggs; ++q)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) o[q * NF + j] = acc[q][j];
+}
+
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_coarse_sum(const Ctx c) {
+  const int g = blockIdx.x, n = c.ncoarse;
+  for (int idx = threadIdx.x; idx < NF * n; idx += kVecBlock) {
+    const int i = idx / n, col = idx - i * n, h = col / NF, j = col - h * NF;
+    double s = 0.0;
+    for (int I = c.agg_start[g]; I < c.agg_start[g + 1]; ++I) {
+      const int32_t* ra = c.row_aggs + (size_t)I * kMaxRowAggs;
+#pragma unroll
+      for (int q = 0; q < kMaxRowAggs; ++q)
+        if (ra[q] == h) s += c.AP[((size_t)(I * NF + i) * kMaxRowAggs + q) * NF + j];
+    }
+    c.Ac[(size_t)(g * NF + i) * n + col] = s;
+  }
+}
+
+// In-place Gauss-Jordan inverse of the coarse operator by one 1024-thread workgroup, matrix resident in LDS.
+__global__ __launch_bounds__(1024) void k_coarse_invert(const Ctx c) {
+  extern __shared__ double sm[];
+  const int n = c.ncoarse, t = threadIdx.x, nt = blockDim.x;
+  double* A = sm;               // n*n
+  double* rowk = A + n * n;     // n
+  double* colk = rowk + n;      // n
+  double* redv = colk + n;      // 16
+  int* redi = (int*)(redv + 16);   // 16
+  int* piv = redi + 16;         // n
+  __shared__ int sing;
+  if (t == 0) sing = 0;
+  for (int q = t; q < n * n; q += nt) A[q] = c.Ac[q];
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    // pivot search in column k, rows k..n-1 (n <= 192: three waves hold one candidate each lane)
+    double v = -1.0; int idx = k;
+    if (t < 192) { const int r = t; if (r >= k && r < n) { v = fabs(A[r * n + k]); idx = r; } }
+    if (t < 192) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if ((t & 63) == 0) { redv[t >> 6] = v; redi[t >> 6] = idx; }
+    }
+    __syncthreads();
+    if (t == 0) {
+      double bv = redv[0]; int bi = redi[0];
+      for (int w = 1; w < 3; ++w) if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+      piv[k] = bi;
+      if (!(bv > 0.0)) sing = 1;
+    }
+    __syncthreads();
+    if (sing) break;
+    const int p = piv[k];
+    if (p != k && t < n) { const double tmp = A[k * n + t]; A[k * n + t] = A[p * n + t]; A[p * n + t] = tmp; }
+    __syncthreads();
+    const double ip = 1.0 / A[k * n + k];
+    if (t < n) colk[t] = A[t * n + k];
+    __syncthreads();
+    if (t < n) rowk[t] = (t == k) ? ip : A[k * n + t] * ip;
+    __syncthreads();
+    for (int q = t; q < n * n; q += nt) {
+      const int r = q / n, cc = q - r * n;
+      if (r == k) A[q] = rowk[cc];
+      else A[q] = ((cc == k) ? 0.0 : A[q]) - colk[r] * rowk[cc];
+    }
+    __syncthreads();
+  }
+  if (sing) { if (t == 0) atomicOr(c.status, 4); return; }
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = piv[k];
+    if (p != k && t < n) { const double tmp = A[t * n + k]; A[t * n + k] = A[t * n + p]; A[t * n + p] = tmp; }
+    __syncthreads();
+  }
+  for (int q = t; q < n * n; q += nt) { const int r = q / n, cc = q - r * n; c.AciT[(size_t)cc * n + r] = A[q]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coarse solve: pc = sum of the restriction partials of each aggregate (fixed order), yc = Aci pc.
+// One workgroup; thread (row, chunk) with 4 column chunks.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(1024) void k_coarse(const Ctx c, int use_coarse) {
+  __shared__ double pc[kMaxCoarse];
+  __shared__ double red[4][kMaxCoarse];
+  if (c.scal->done) return;
+  const int n = c.ncoarse, t = threadIdx.x;
+  if (!use_coarse) { if (t < n) c.yc[t] = 0.0; return; }
+  if (t < n) {
+    const int g = t / NF, f = t - g * NF;
+    double s = 0.0;
+    for (int w = c.agg_vw_ptr[g]; w < c.agg_vw_ptr[g + 1]; ++w) s += c.pc_part[(size_t)w * NF + f];
+    pc[t] = s;
+  }
+  __syncthreads();
+  const int row = t % kMaxCoarse, ch = t / kMaxCoarse;  // 1024 threads -> 7 chunks available, use 4
+  if (ch < 4 && row < n) {
+    const int c0 = (n * ch) / 4, c1 = (n * (ch + 1)) / 4;
+    double s = 0.0;
+    for (int cc = c0; cc < c1; ++cc) s += c.AciT[(size_t)cc * n + row] * pc[cc];
+    red[ch][row] = s;
+  }
+  __syncthreads();
+  if (t < n) c.yc[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SELL block SpMV: out = A (x + P yc).  One workgroup (4 waves) per slice, the waves split the block
+// columns; lane = (block row in slice, scalar row).  Every value load is a 512-byte contiguous wave read.
+// MODE 0: plain.  MODE 1: part_a = (rhat, out).  MODE 2: part_b = (out,s) (out,out) (rhat,s) (rhat,out).
+// ---------------------------------------------------------------------------------------------
+template <int NF, int MODE>
+__global__ __launch_bounds__(kVecBlock) void k_spmv(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
+  constexpr int S = kWave / NF;
+  __shared__ double red[4][64];
+  if (MODE != 0 && c.scal->done) return;
+  const int s = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Iloc = lane / NF, i = lane - Iloc * NF;
+  const int I = s * S + Iloc;
+  const bool active = (Iloc < S) && (I < c.nv);
+  double acc = 0.0;
+  if (active) {
+    const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
+    const double* base = c.vals + c.slice_off[s] + lane;
+    for (int kp = w; kp < mx; kp += 4) {
+      const int col = c.sell_cols[(size_t)(cb + kp) * kSlicePad + Iloc];
+      const double* xv = x + (size_t)col * NF;
+      const double* yv = c.yc + c.agg[col] * NF;
+      const double* av = base + (size_t)kp * NF * kWave;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc += av[(size_t)j * kWave] * (xv[j] + yv[j]);
+    }
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w != 0) return;
+  const double tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int r = I * NF + i;
+  if (active) out[r] = tot;
+  if (MODE == 1) {
+    const double d = wave_sum(active ? c.krhat[r] * tot : 0.0);
+    if (lane == 0) c.part_a[s] = d;
+  } else if (MODE == 2) {
+    const double sv = active ? c.ks[r] : 0.0, rh = active ? c.krhat[r] : 0.0, tv = active ? tot : 0.0;
+    const double d0 = wave_sum(tv * sv), d1 = wave_sum(tv * tv), d2 = wave_sum(rh * sv), d3 = wave_sum(rh * tv);
+    if (lane == 0) {
+      c.part_b[s] = d0; c.part_b[c.nslices + s] = d1; c.part_b[2 * c.nslices + s] = d2; c.part_b[3 * c.nslices + s] = d3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BiCGStab vector kernels.  Workgroup = whole nodes of ONE aggregate (so the restriction partial is a
+// per-workgroup sum), thread = dof.  Right preconditioning: the Krylov space lives on y, x = M^{-1} y.
+//
+// k_vec1: (iteration > 0) omega = (t,s)/(t,t); y += alpha p + omega s; r = s - omega t;
+//         rho' = (rhat,s) - omega (rhat,t); beta = (rho'/rho)(alpha/omega); p = r + beta (p - omega v)
+//         (iteration 0)  p = r
+//         then q = Dinv p, restriction partial of p, partial of (r,r).
+// k_vec2: convergence test on (r,r); alpha = rho'/(rhat,v); s = r - alpha v; q = Dinv s; restriction of s.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__device__ inline void dinv_restrict(const Ctx& c, int wg, int n0, int nnodes, int tid, bool valid, double val,
+                                     double* lv /* [kVecBlock] */) {
+  lv[tid] = valid ? val : 0.0;
+  __syncthreads();
+  if (valid) {
+    const int r = n0 * NF + tid, nl = tid / NF;
+    const double* d = c.Dinv + (size_t)r * NF;
+    double q = 0.0;
+#pragma unroll
+    for (int mI = 0; mI < NF; ++mI) q += d[mI] * lv[nl * NF + mI];
+    c.kq[r] = q;
+  }
+  if (tid < NF) {
+    double s = 0.0;
+    for (int nl = 0; nl < nnodes; ++nl) s += lv[nl * NF + tid];
+    c.pc_part[(size_t)wg * NF + tid] = s;
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_vec1(const Ctx c) {
+  __shared__ double lv[kVecBlock];
+  __shared__ double lred[16];
+  KrylovScalars* sc = c.scal;
+  if (sc->done) return;
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
+  const bool valid = tid < nnodes * NF;
+  const int r = n0 * NF + tid;
+  const bool first = (sc->iters == 0);
+  double pv = 0.0, rn = 0.0, rho_next;
+  if (first) {
+    rho_next = sc->rho;
+    if (valid) { rn = c.kr[r]; pv = rn; }
+  } else {
+    double tot[4];
+    sum_partials<4>(c.part_b, c.nslices, c.nslices, tot, lred);
+    const double ts = tot[0], tt = tot[1], rs = tot[2], rt = tot[3];
+    const double alpha = sc->alpha, rho = sc->rho;
+    const double omega = ts / tt;
+    rho_next = rs - omega * rt;
+    const double beta = (rho_next / rho) * (alpha / omega);
+    if (valid) {
+      const double sv = c.ks[r], tv = c.kt[r], pold = c.kp[r];
+      c.ky[r] += alpha * pold + omega * sv;
+      rn = sv - omega * tv;
+      c.kr[r] = rn;
+      pv = rn + beta * (pold - omega * c.kv[r]);
+    }
+  }
+  if (valid) c.kp[r] = pv;
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, pv, lv);
+  double v[1] = {rn * rn};
+  block_sum<1>(v, lred);
+  if (tid == 0) {
+    c.part_rr[wg] = v[0];
+    if (wg == 0) { sc->rho_next = rho_next; sc->it_cur = first ? 0 : sc->iters; }
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_vec2(const Ctx c) {
+  __shared__ double lv[kVecBlock];
+  __shared__ double lred[16];
+  KrylovScalars* sc = c.scal;
+  if (sc->done) return;
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  double rr[1], rv[1];
+  sum_partials<1>(c.part_rr, c.n_vecwg, c.n_vecwg, rr, lred);
+  sum_partials<1>(c.part_a, c.nslices, c.nslices, rv, lred);
+  // vec2 only reads scalars that vec1 (the previous launch) wrote and only writes scalars that vec1 reads
+  const double rho_next = sc->rho_next;
+  const int iters = sc->it_cur;
+  int done = 0;
+  if (!(rr[0] == rr[0]) || !(rv[0] == rv[0])) done = 3;                  // NaN
+  else if (sqrt(rr[0]) <= sc->tol) done = 1;
+  else if (iters >= sc->max_iters) done = 2;
+  else if (rv[0] == 0.0 || rho_next == 0.0) done = 3;                    // breakdown
+  if (done) {
+    // scalars are only written here, after every workgroup has passed its own (identical) test
+    if (wg == 0 && tid == 0) { sc->rr = rr[0]; sc->done = done; }
+    return;
+  }
+  const double alpha = rho_next / rv[0];
+  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
+  const bool valid = tid < nnodes * NF;
+  const int r = n0 * NF + tid;
+  double sv = 0.0;
+  if (valid) { sv = c.kr[r] - alpha * c.kv[r]; c.ks[r] = sv; }
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, sv, lv);
+  if (wg == 0 && tid == 0) { sc->alpha = alpha; sc->rho = rho_next; sc->rr = rr[0]; sc->iters = iters + 1; }
+}
+
+// x = M^{-1} y = Dinv y + P Aci P^T y, in three steps: k_vec_final (q = Dinv y, restrict y), k_coarse, k_apply.
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_vec_final(const Ctx c) {
+  __shared__ double lv[kVecBlock];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
+  const bool valid = tid < nnodes * NF;
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, valid ? c.ky[n0 * NF + tid] : 0.0, lv);
+}
+
+// dst[r] = scale_dst * dst[r] + scale_x * (q[r] + yc[agg]);  Newton update: u -= omega dx  (scale_dst 1, scale_x -omega)
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_apply(const Ctx c, double* __restrict__ dst, double scale_dst, double scale_x) {
+  const int r = blockIdx.x * kVecBlock + threadIdx.x;
+  if (r >= c.ndof) return;
+  const int I = r / NF, f = r - I * NF;
+  const double x = c.kq[r] + c.yc[c.agg[I] * NF + f];
+  dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * x;
+}
+
+__global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double v = src[i]; a[i] = v; if (b) b[i] = v; }
+}
+
+__global__ void k_fill(double* __restrict__ a, double v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+}  // namespace gmpnp

@@ -1,0 +1,196 @@
+"""Flat description of one GMPNP weak-form family member.
+
+The reference builds its forms symbolically in UFL (1D/MPNP_CO2ER_EDL.py:383-595,
+3D/MPNP_CO2ER_pore.py:474-769).  Both scripts instantiate the same family
+
+    F_i = ((u_i-u_i^n)/Delta) v + grad u_i.grad v + z_i u_i grad p.grad v - R_i(u) v
+          + [u_i/(1-S)] G.grad v  (+ boundary fluxes),      S = sum_j a_j u_j, G = sum_j a_j grad u_j
+    F_p = -eps(u) grad p.grad v + q (sum_j z_j bulk_j u_j) v
+
+with R_i at most quadratic in u and eps affine in u, so a model is a handful of coefficient tables.
+``Model`` holds them; ``CModel`` is the bit-identical ctypes image of ``gmpnp_model_t``
+(include/gmpnp.h) that crosses the C-ABI.  The oracle consumes ``Model`` directly.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MAX_SPECIES = 8
+MAX_BILINEAR = 4
+MAX_QUAD = 16
+
+
+@dataclass
+class Model:
+    dim: int
+    species: list  # names, mixed-space order (reference 3D:412-422, 1D:310-317); potential is last
+    z: np.ndarray  # (ns,) charges
+    bulk: np.ndarray  # (ns,) scaling concentrations [mol/m3]
+    a: np.ndarray  # (ns,) scale_vol (reference 3D:286-287, 1D:199-200)
+    inv_dt: float  # 1/Delta: 1/del_t (3D:534) or 1/(del_t*L_D) (1D:458)
+    q: float  # F^2 L^2/(eps0 R T) (3D:280, 1D:193)
+    eps0: float  # eps(u) = eps0 + sum_j epsc_j u_j   (3D:752-760)
+    epsc: np.ndarray
+    rc0: np.ndarray  # (ns,)      -R_i = rc0_i + sum_j rc1_ij u_j + sum_t rc2_it u_{bj_t} u_{bk_t}
+    rc1: np.ndarray  # (ns,ns)
+    bil: list  # [(j,k), ...] species index pairs of the bilinear monomials
+    rc2: np.ndarray  # (ns,nbil)
+    steric: bool = True  # MPNP (True) or PNP (False, 1D:429-455)
+    wall_flux: np.ndarray = None  # (ns,) Neumann J_X on ds(2)            (3D:474-481)
+    exit_kappa: np.ndarray = None  # (ns,) Robin kappa_X (u_X-1) on ds(3)   (3D:484-499)
+    point_flux: np.ndarray = None  # (ns,) 1D point fluxes at the OHP vertex (1D:371-375,553,738)
+
+    def __post_init__(self):
+        ns = len(self.species)
+        for name in ("wall_flux", "exit_kappa", "point_flux"):
+            if getattr(self, name) is None:
+                setattr(self, name, np.zeros(ns))
+
+    @property
+    def n_species(self) -> int:
+        return len(self.species)
+
+    @property
+    def n_fields(self) -> int:
+        return len(self.species) + 1
+
+
+class CModel(ctypes.Structure):
+    """ctypes image of ``gmpnp_model_t`` (include/gmpnp.h)."""
+
+    _fields_ = [
+        ("dim", ctypes.c_int32),
+        ("n_species", ctypes.c_int32),
+        ("n_bilinear", ctypes.c_int32),
+        ("steric", ctypes.c_int32),
+        ("inv_dt", ctypes.c_double),
+        ("q", ctypes.c_double),
+        ("eps0", ctypes.c_double),
+        ("z", ctypes.c_double * MAX_SPECIES),
+        ("a", ctypes.c_double * MAX_SPECIES),
+        ("qzb", ctypes.c_double * MAX_SPECIES),
+        ("epsc", ctypes.c_double * MAX_SPECIES),
+        ("rc0", ctypes.c_double * MAX_SPECIES),
+        ("rc1", (ctypes.c_double * MAX_SPECIES) * MAX_SPECIES),
+        ("rc2", (ctypes.c_double * MAX_BILINEAR) * MAX_SPECIES),
+        ("bil_j", ctypes.c_int32 * MAX_BILINEAR),
+        ("bil_k", ctypes.c_int32 * MAX_BILINEAR),
+        ("wall_flux", ctypes.c_double * MAX_SPECIES),
+        ("exit_kappa", ctypes.c_double * MAX_SPECIES),
+        ("point_flux", ctypes.c_double * MAX_SPECIES),
+    ]
+
+
+def to_cmodel(m: Model) -> CModel:
+    ns = m.n_species
+    if ns > MAX_SPECIES or len(m.bil) > MAX_BILINEAR:
+        raise ValueError("model exceeds GMPNP_MAX_SPECIES / GMPNP_MAX_BILINEAR")
+    c = CModel()
+    c.dim, c.n_species, c.n_bilinear, c.steric = m.dim, ns, len(m.bil), int(bool(m.steric))
+    c.inv_dt, c.q, c.eps0 = float(m.inv_dt), float(m.q), float(m.eps0)
+    for i in range(ns):
+        c.z[i] = float(m.z[i])
+        c.a[i] = float(m.a[i])
+        c.qzb[i] = float(m.q) * float(m.z[i]) * float(m.bulk[i])
+        c.epsc[i] = float(m.epsc[i])
+        c.rc0[i] = float(m.rc0[i])
+        c.wall_flux[i] = float(m.wall_flux[i])
+        c.exit_kappa[i] = float(m.exit_kappa[i])
+        c.point_flux[i] = float(m.point_flux[i])
+        for j in range(ns):
+            c.rc1[i][j] = float(m.rc1[i, j])
+        for t in range(len(m.bil)):
+            c.rc2[i][t] = float(m.rc2[i, t])
+    for t, (j, k) in enumerate(m.bil):
+        c.bil_j[t], c.bil_k[t] = int(j), int(k)
+    return c
+
+
+# ---------------------------------------------------------------------------------------------
+# Quadrature for the only non-polynomial integrand, the steric quotient u_i/(1-S)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Quadrature:
+    """Barycentric points ``lam`` (nq, dim+1) and weights summing to 1 for the residual (``f``) and
+    Jacobian (``j``) cell integrals.  UFL's degree estimation gives 3 for F and 4 for J (SURVEY
+    §3.3 item 7); FFC then asks FIAT for its default scheme of that degree.  [3P, parity
+    unpinned: FIAT is not in /root/reference; the tables below restate FIAT 2019.1
+    ``quadrature_schemes.py`` from its published sources (Zienkiewicz-Taylor 5-point degree-3 rule,
+    Keast 14-point degree-4 rule, Gauss-Legendre on the interval) and tests/test_quadrature.py
+    checks each rule integrates every monomial up to its degree exactly.]"""
+
+    lam_f: np.ndarray
+    w_f: np.ndarray
+    lam_j: np.ndarray
+    w_j: np.ndarray
+
+
+def _from_ref_points(x: np.ndarray) -> np.ndarray:
+    x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+    return np.concatenate([1.0 - x.sum(axis=1, keepdims=True), x], axis=1)
+
+
+def _tet_degree3():
+    x = [[0.25, 0.25, 0.25], [0.5, 1 / 6, 1 / 6], [1 / 6, 0.5, 1 / 6], [1 / 6, 1 / 6, 0.5], [1 / 6, 1 / 6, 1 / 6]]
+    w = np.array([-0.8, 0.45, 0.45, 0.45, 0.45])
+    return _from_ref_points(x), w
+
+
+def _tet_degree4():
+    a, b = 0.1005267652252045, 0.3143728734931922
+    a1, b1 = 1.0 - 3.0 * a, 1.0 - 3.0 * b
+    x = [[0, .5, .5], [.5, 0, .5], [.5, .5, 0], [.5, 0, 0], [0, .5, 0], [0, 0, .5],
+         [a1, a, a], [a, a, a], [a, a, a1], [a, a1, a],
+         [b1, b, b], [b, b, b], [b, b, b1], [b, b1, b]]
+    w = np.array([0.0190476190476190] * 6 + [0.0885898247429807] * 4 + [0.1328387466855907] * 4)
+    return _from_ref_points(x), w
+
+
+def _gauss_legendre(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return _from_ref_points(0.5 * (x + 1.0)[:, None]), 0.5 * w
+
+
+def default_quadrature(dim: int) -> Quadrature:
+    """The reference's rules: degree 3 for F, degree 4 for J."""
+    if dim == 3:
+        lf, wf = _tet_degree3()
+        lj, wj = _tet_degree4()
+    elif dim == 1:
+        lf, wf = _gauss_legendre(2)  # ceil((3+1)/2)
+        lj, wj = _gauss_legendre(3)  # ceil((4+1)/2)
+    else:
+        raise ValueError("dim must be 1 or 3")
+    return Quadrature(lf, wf, lj, wj)
+
+
+class CQuadrature(ctypes.Structure):
+    """ctypes image of ``gmpnp_quadrature_t`` (include/gmpnp.h)."""
+
+    _fields_ = [
+        ("nq_f", ctypes.c_int32),
+        ("nq_j", ctypes.c_int32),
+        ("lam_f", (ctypes.c_double * 4) * MAX_QUAD),
+        ("w_f", ctypes.c_double * MAX_QUAD),
+        ("lam_j", (ctypes.c_double * 4) * MAX_QUAD),
+        ("w_j", ctypes.c_double * MAX_QUAD),
+    ]
+
+
+def to_cquadrature(qd: Quadrature) -> CQuadrature:
+    c = CQuadrature()
+    c.nq_f, c.nq_j = len(qd.w_f), len(qd.w_j)
+    if c.nq_f > MAX_QUAD or c.nq_j > MAX_QUAD:
+        raise ValueError("quadrature exceeds GMPNP_MAX_QUAD points")
+    for q in range(c.nq_f):
+        c.w_f[q] = float(qd.w_f[q])
+        for b in range(qd.lam_f.shape[1]):
+            c.lam_f[q][b] = float(qd.lam_f[q, b])
+    for q in range(c.nq_j):
+        c.w_j[q] = float(qd.w_j[q])
+        for b in range(qd.lam_j.shape[1]):
+            c.lam_j[q][b] = float(qd.lam_j[q, b])
+    return c

@@ -1,0 +1,199 @@
+/* gmpnp.h — C ABI of libgmpnp.so: MI355X (gfx950) backend for the GMPNP time-stepping Newton solve.
+ *
+ * Drop-in boundary.  The reference has no native code and no FFI; the operator API of its
+ * hot path is the FEniCS call
+ *     solve(F == 0, u, bcs, solver_parameters={'nonlinear_solver':'newton','newton_solver':{...}})
+ * at 3D/MPNP_CO2ER_pore.py:789-799 and 1D/MPNP_CO2ER_EDL.py:717,729,737, fed by the objects built at
+ * 3D:329-332 (Mesh), 3D:368-382 (boundary markers / ds), 3D:404-409 (MixedElement([P1]*9)),
+ * 3D:425-432 (u, u_n), 3D:460-467 (DirichletBC list), 3D:474-769 (forms), 3D:856 (u_n.assign(u)) and
+ * their 1D counterparts (1D:231-234, 300-306, 320-326, 350-355, 383-595, 796).  Each entry point below
+ * names the reference construct it replaces.  A reference-side binding is a ctypes stub
+ * (INTEGRATION.md).
+ *
+ * Conventions: plain C types; caller-allocated contiguous fp64 / int32 / int64 host buffers; all
+ * vertex-indexed data in mesh-FILE vertex order, dof = vertex * n_fields + field (fields = species in
+ * mixed-space order, potential last); the library owns all device memory behind the opaque handle;
+ * every function returns 0 or a negative gmpnp_status and never throws; one host thread and one HIP
+ * stream per handle; calls block until the result is on the host.
+ */
+#ifndef GMPNP_H
+#define GMPNP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMPNP_MAX_SPECIES 8
+#define GMPNP_MAX_BILINEAR 4
+#define GMPNP_MAX_QUAD 16
+#define GMPNP_MAX_NEWTON_HISTORY 64
+
+typedef enum {
+  GMPNP_OK = 0,
+  GMPNP_ERR_INVALID = -1,        /* bad argument / unsupported configuration */
+  GMPNP_ERR_HIP = -2,            /* HIP runtime error (see gmpnp_last_error)   */
+  GMPNP_ERR_NOT_CONVERGED = -3,  /* Newton hit maximum_iterations ([3P] error_on_nonconvergence) */
+  GMPNP_ERR_LINEAR = -4,         /* Krylov breakdown / did not reach tolerance / singular block */
+  GMPNP_ERR_NUMERIC = -5         /* NaN residual or 1 - sum_j a_j u_j <= 0 at a quadrature point */
+} gmpnp_status;
+
+/* Coefficient tables of one member of the GMPNP weak-form family (replaces the UFL forms
+ * 3D:505-769 / 1D:383-595 and the Constants feeding them 3D:261-324,474-499 / 1D:178-208,371-375).
+ *   -R_i(u) = rc0_i + sum_j rc1_ij u_j + sum_t rc2_it u_{bil_j[t]} u_{bil_k[t]}
+ *   eps(u)  = eps0 + sum_j epsc_j u_j ;  charge term  sum_j qzb_j u_j  (qzb_j = q z_j bulk_j)        */
+typedef struct {
+  int32_t dim;        /* 1 (interval) or 3 (tetrahedron) */
+  int32_t n_species;  /* 6 (1D) or 8 (3D); n_fields = n_species + 1 */
+  int32_t n_bilinear;
+  int32_t steric;     /* 1 = MPNP (u_i/(1-S) term), 0 = PNP */
+  double inv_dt;      /* 1/del_t (3D:534) or 1/(del_t*L_D) (1D:458) */
+  double q;
+  double eps0;
+  double z[GMPNP_MAX_SPECIES];
+  double a[GMPNP_MAX_SPECIES];    /* scale_vol */
+  double qzb[GMPNP_MAX_SPECIES];
+  double epsc[GMPNP_MAX_SPECIES];
+  double rc0[GMPNP_MAX_SPECIES];
+  double rc1[GMPNP_MAX_SPECIES][GMPNP_MAX_SPECIES];
+  double rc2[GMPNP_MAX_SPECIES][GMPNP_MAX_BILINEAR];
+  int32_t bil_j[GMPNP_MAX_BILINEAR];
+  int32_t bil_k[GMPNP_MAX_BILINEAR];
+  double wall_flux[GMPNP_MAX_SPECIES];   /* J_X_wall on ds(2)            3D:474-481 */
+  double exit_kappa[GMPNP_MAX_SPECIES];  /* kappa_X (u_X - 1) on ds(3)   3D:484-499 */
+  double point_flux[GMPNP_MAX_SPECIES];  /* J_X at the OHP vertex        1D:371-375,553,738 */
+} gmpnp_model_t;
+
+/* Quadrature of the rational steric integrand: barycentric points (first dim+1 entries of each row
+ * used) and weights summing to 1, for the residual (degree 3) and the Jacobian (degree 4) — replaces the
+ * FFC/FIAT-generated rules ([3P]). */
+typedef struct {
+  int32_t nq_f, nq_j;
+  double lam_f[GMPNP_MAX_QUAD][4];
+  double w_f[GMPNP_MAX_QUAD];
+  double lam_j[GMPNP_MAX_QUAD][4];
+  double w_j[GMPNP_MAX_QUAD];
+} gmpnp_quadrature_t;
+
+/* Mesh + boundary facet sets — replaces Mesh(...) 3D:329-332 / 1D:231-234, the marked ds measure
+ * 3D:368-382 and FunctionSpace(mesh, MixedElement([P1]*n)) 3D:404-408 / 1D:300-304. */
+typedef struct {
+  int32_t dim;
+  int32_t n_vertices;
+  int32_t n_cells;
+  const double* coords;        /* [n_vertices][dim] */
+  const int32_t* cells;        /* [n_cells][dim+1]  */
+  const int32_t* perm;         /* [n_vertices] internal->file vertex order, or NULL (identity).
+                                  Contiguous internal ranges become the coarse-space aggregates and
+                                  the multi-GPU partitions, so pass a slab ordering (see
+                                  gmpnp_amd.backend.slab_permutation). */
+  int32_t n_wall_facets;
+  const int32_t* wall_facets;  /* [n][3] vertex triples of the exterior facets in ds(2) */
+  int32_t n_exit_facets;
+  const int32_t* exit_facets;  /* [n][3] ds(3) */
+  int32_t n_point_vertices;
+  const int32_t* point_vertices; /* 1D: vertices that receive model.point_flux */
+} gmpnp_mesh_t;
+
+/* Linear solver for J dx = b (replaces PETSc KSP preonly + LU: 'mumps' 3D:792, default LU 1D:357-364). */
+typedef enum {
+  GMPNP_LINEAR_BICGSTAB_TWOLEVEL = 0, /* BiCGStab, right-preconditioned by node-block Jacobi + slab-aggregate coarse correction */
+  GMPNP_LINEAR_BICGSTAB_JACOBI = 1,   /* BiCGStab, node-block Jacobi only ([3P] 'bicgstab' + 'jacobi') */
+  GMPNP_LINEAR_BLOCK_TRIDIAGONAL = 2  /* direct block-tridiagonal LU (1D meshes only) */
+} gmpnp_linear_kind;
+
+/* newton_solver parameter dict of the reference (3D:789-798, 1D:357-364) + krylov_solver sub-dict. */
+typedef struct {
+  int32_t maximum_iterations;   /* 50 */
+  double relative_tolerance;    /* 1e-4 */
+  double absolute_tolerance;    /* 1e-4 */
+  double relaxation_parameter;  /* 0.9 (3D), 1.0 (1D) */
+  int32_t linear_solver;        /* gmpnp_linear_kind */
+  double krylov_relative_tolerance; /* on ||b - A x|| / ||b||; 1e-10 ~ "exact-equivalent" */
+  double krylov_absolute_tolerance;
+  int32_t krylov_maximum_iterations;
+} gmpnp_newton_options_t;
+
+typedef struct {
+  int32_t iterations;           /* Newton iterations performed ([3P] "Newton iteration k") */
+  int32_t converged;
+  int32_t krylov_iterations;    /* total over the solve */
+  int32_t n_residuals;          /* iterations + 1 */
+  double residuals[GMPNP_MAX_NEWTON_HISTORY]; /* ||b||_2 before iteration 0 and after each update */
+  int32_t krylov_per_iteration[GMPNP_MAX_NEWTON_HISTORY];
+  double ms_assemble, ms_setup, ms_krylov, ms_total; /* host wall clock, ms */
+} gmpnp_newton_stats_t;
+
+typedef struct {
+  int32_t iterations;
+  int32_t converged;
+  double residual_norm;   /* recurrence ||r||_2 at exit */
+  double rhs_norm;
+} gmpnp_linear_stats_t;
+
+/* Creation-time tunables (no reference counterpart). Zero-initialise for defaults. */
+typedef struct {
+  int32_t device_id;      /* HIP device ordinal */
+  int32_t n_aggregates;   /* coarse-space slabs; 0 = default (largest allowed by the LDS-resident coarse inverse) */
+  int32_t use_graph;      /* 0 = default (on): replay Krylov iterations from a captured hipGraph; 2 = off */
+  int32_t krylov_batch;   /* iterations launched between convergence read-backs; 0 = default */
+  int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */
+} gmpnp_options_t;
+
+typedef struct gmpnp_solver gmpnp_solver;
+
+const char* gmpnp_version(void);
+/* Message of the most recent failure on this thread. */
+const char* gmpnp_last_error(void);
+
+/* Mesh + FunctionSpace + forms -> device-resident problem. u and u_n start as zeros ([3P] Function(V), 3D:425). */
+int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                 const gmpnp_options_t* opts, gmpnp_solver** out);
+void gmpnp_destroy(gmpnp_solver* s);
+
+/* Re-upload constants (Constant(...) objects rebuilt between steps: del_t 1D:639-642 (Q2), J_OH/J_H 1D:789-793). */
+int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model);
+
+/* bcs list after DOLFIN's in-order application (later wins): unique dofs + values (3D:460-467,835-838; 1D:350-355). */
+int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values);
+
+/* u / u_n contents (either pointer may be NULL to leave that vector untouched). interpolate 3D:432, project 1D:326. */
+int gmpnp_set_state(gmpnp_solver* s, const double* u, const double* u_n);
+/* compute_vertex_values() of all fields at once (3D:802-813, 1D:745-753). */
+int gmpnp_get_state(gmpnp_solver* s, double* u_out, double* u_n_out);
+/* u_n.assign(u) (3D:856, 1D:796), on device. */
+int gmpnp_assign_previous(gmpnp_solver* s);
+
+/* solve(F == 0, u, bcs, solver_parameters) (3D:789-799, 1D:737-742): damped Newton on the device state u.
+ * Returns GMPNP_ERR_NOT_CONVERGED where DOLFIN raises RuntimeError; stats are filled either way. */
+int gmpnp_newton_solve(gmpnp_solver* s, const gmpnp_newton_options_t* opts, gmpnp_newton_stats_t* stats);
+
+/* ---- lower-level hooks for parity tests and benchmarks ([3P] assemble / DirichletBC.apply / KSP) ---- */
+int32_t gmpnp_n_fields(const gmpnp_solver* s);
+int64_t gmpnp_n_dofs(const gmpnp_solver* s);
+int64_t gmpnp_n_blocks(const gmpnp_solver* s);   /* node blocks of the BSR Jacobian */
+int64_t gmpnp_jacobian_nnz(const gmpnp_solver* s); /* n_blocks * n_fields^2 */
+int32_t gmpnp_n_aggregates(const gmpnp_solver* s);
+
+/* b = assemble(F) with bc rows b = x - g; optionally A = assemble(J) with identity bc rows (kept on device).
+ * F_out (n_dofs) and norm_out may be NULL. */
+int gmpnp_assemble(gmpnp_solver* s, int32_t want_jacobian, double* F_out, double* norm_out);
+/* Current device Jacobian as CSR in file-order dof numbering, columns ascending (indptr n_dofs+1, others nnz). */
+int gmpnp_get_jacobian_csr(gmpnp_solver* s, int32_t* indptr, int32_t* indices, double* data);
+/* y = J x with the current device Jacobian. */
+int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y);
+/* Solve J x = b with the current device Jacobian (preconditioner is rebuilt). */
+int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t linear_solver, double rtol,
+                       double atol, int32_t max_iterations, gmpnp_linear_stats_t* stats);
+
+/* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
+ * events; kernel: 0 = Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather. */
+int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
+/* SpMV launches sampled with HIP events since the last call (opts.profile_every): count, mean microseconds. */
+int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMPNP_H */
