@@ -201,6 +201,8 @@ class DeviceSolver:
         m.n_exit_facets, m.exit_facets = len(self._exit), _iptr(self._exit)
         m.n_point_vertices, m.point_vertices = len(self._pts), _iptr(self._pts)
         cm, cq = to_cmodel(problem.model), to_cquadrature(problem.quad)
+        if os.environ.get("GMPNP_USE_GRAPH", "1") == "0":
+            use_graph = False
         opts = COptions(device_id, n_aggregates, 0 if use_graph else 2, krylov_batch, profile_every)
         h = c_void_p()
         self._h = None

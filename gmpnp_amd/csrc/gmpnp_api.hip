@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -65,10 +66,10 @@ struct gmpnp_solver {
   std::vector<int32_t> wall_f, exit_f, point_v;
   // device storage
   DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
-  DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, Dinv, AP, Ac, AciT;
+  DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, Dinv, AP, AcPart, Ac, AciT;
   DevBuf<double> kr, krhat, kp, kv, ks, kt, ky, kq, pc_part, yc, part_rr, part_a, part_b, part_f, tmpx;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
-      sell_cols, wl_slice, wl_kpos, diag_kpos, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
+      sell_cols, sell_blk, wl_slice, wl_kpos, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
   DevBuf<int64_t> rob_addr, slice_off;
   DevBuf<uint8_t> bcflag, sell_aggslot;
   DevBuf<KrylovScalars> scal;
@@ -78,18 +79,20 @@ struct gmpnp_solver {
   // Krylov graph (one per preconditioner mode)
   hipGraphExec_t graph[2] = {nullptr, nullptr};
   int graph_iters = 4;
-  int last_krylov_iters = 0;
+  int last_krylov_iters[2] = {0, 0};
   bool jacobian_valid = false, precond_valid = false;
   int precond_mode = -1;
   // SpMV event sampling (eager mode)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   int64_t spmv_launched = 0, spmv_sampled = 0; double spmv_us_sum = 0.0;
   hipEvent_t ev_phase[6] = {};
+  hipEvent_t ev_poll[2] = {};
 
   ~gmpnp_solver() {
     for (auto& g : graph) if (g) (void)hipGraphExecDestroy(g);
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : ev_phase) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_poll) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
     if (h_part) (void)hipHostFree(h_part);
     if (h_status) (void)hipHostFree(h_status);
@@ -108,6 +111,8 @@ namespace {
   } while (0)
 
 int grid_for(int n, int block) { return (n + block - 1) / block; }
+
+size_t coarse_lds_bytes(int n, int nf) { return (size_t)(n * n + n * nf + 2 * nf * nf) * sizeof(double); }
 
 // Facet / point integrals that do not depend on u, and the Robin mass entries (SURVEY App. D "facets").
 int rebuild_boundary(gmpnp_solver* s) {
@@ -154,7 +159,7 @@ int rebuild_boundary(gmpnp_solver* s) {
     const int row = ents[k].row, col = ents[k].col;
     const int I = row / nf, i = row % nf, J = col / nf, jf = col % nf;
     const int32_t* b = t.cols.data() + t.rowptr[I]; const int32_t* e = t.cols.data() + t.rowptr[I + 1];
-    const int kpos = (int)(std::lower_bound(b, e, J) - b);
+    const int kpos = t.sellk[(int)(std::lower_bound(b, e, J) - t.cols.data())];
     const int sl = I / t.S, il = I - sl * t.S;
     rrow.push_back(row); rcol.push_back(col); rval.push_back(v);
     raddr.push_back(t.slice_off[sl] + (int64_t)(kpos * nf + jf) * kWave + il * nf + i);
@@ -227,10 +232,10 @@ int setup_preconditioner(gmpnp_solver* s, int mode) {
   hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 64)), dim3(64), 0, s->stream, s->c);
   if (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) {
     hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
-    hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg), dim3(kVecBlock), 0, s->stream, s->c);
+    hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, s->stream, s->c);
     const int n = s->ncoarse;
-    const size_t lds = (size_t)(n * n + 2 * n + 16) * sizeof(double) + (size_t)(16 + n) * sizeof(int);
-    hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(1024), lds, s->stream, s->c);
+    hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
+    hipLaunchKernelGGL((k_coarse_invert<NF>), dim3(1), dim3(512), coarse_lds_bytes(n, NF), s->stream, s->c);
   }
   HIP_TRY(hipGetLastError());
   s->precond_valid = true; s->precond_mode = mode;
@@ -267,11 +272,11 @@ template <int NF>
 int enqueue_iteration(gmpnp_solver* s, int use_coarse, bool allow_sampling) {
   const int every = s->opts.profile_every;
   hipLaunchKernelGGL((k_vec1<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
   int rc = launch_spmv<NF, 1>(s, s->kq.p, s->kv.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
   if (rc) return rc;
   hipLaunchKernelGGL((k_vec2<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
   rc = launch_spmv<NF, 2>(s, s->kq.p, s->kt.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
   return rc;
 }
@@ -289,7 +294,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   init.rho = bnorm * bnorm; init.rho_next = init.rho; init.alpha = 1.0;
   init.tol = std::max(rtol * bnorm, atol); init.rr = init.rho; init.iters = 0; init.max_iters = maxit; init.done = 0;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
-  *s->h_scal = init;
+  s->h_scal[0] = init;
   HIP_TRY(hipMemcpyAsync(s->scal.p, s->h_scal, sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));  // h_scal is reused for read-back below
   const bool use_graph = (s->opts.use_graph != 2) && s->opts.profile_every == 0;
@@ -305,24 +310,39 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
     HIP_TRY(hipGraphInstantiate(&s->graph[use_coarse], g, nullptr, nullptr, 0));
     HIP_TRY(hipGraphDestroy(g));
   }
-  int launched = 0;
-  int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, s->last_krylov_iters - 2);
-  KrylovScalars res = init;
-  while (!res.done) {
-    int want = (launched == 0) ? first : B;
-    want = ((want + B - 1) / B) * B;
-    for (int k = 0; k < want; k += B) {
+  // Bursts of B iterations.  The first burst is 3/4 of what the previous solve with this preconditioner
+  // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
+  // next burst, then wait for the event), so the read-back latency hides behind queued work.  Kernels of a
+  // converged solve exit at their first instruction.
+  int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, (3 * s->last_krylov_iters[use_coarse]) / 4);
+  first = ((first + B - 1) / B) * B;
+  auto burst = [&](int iters) -> int {
+    for (int k = 0; k < iters; k += B) {
       if (use_graph) HIP_TRY(hipGraphLaunch(s->graph[use_coarse], s->stream));
       else for (int it = 0; it < B; ++it) { int rc = enqueue_iteration<NF>(s, use_coarse, true); if (rc) return rc; }
     }
-    launched += want;
-    HIP_TRY(hipMemcpyAsync(s->h_scal, s->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    res = *s->h_scal;
-    int rc = drain_spmv_events(s); if (rc) return rc;
-    if (launched > maxit + 2 * B && !res.done) break;  // defensive: the device test ends the loop at max_iters
+    return GMPNP_OK;
+  };
+  KrylovScalars res = init;
+  int launched = 0, slot = 0;
+  if (!res.done) {
+    int rc = burst(first); if (rc) return rc;
+    launched = first;
+    while (true) {
+      HIP_TRY(hipMemcpyAsync(&s->h_scal[slot], s->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipEventRecord(s->ev_poll[slot], s->stream));
+      rc = burst(B); if (rc) return rc;  // speculative: overlaps the read-back
+      launched += B;
+      HIP_TRY(hipEventSynchronize(s->ev_poll[slot]));
+      res = s->h_scal[slot];
+      slot ^= 1;
+      if (res.done) break;
+      if (launched > maxit + 4 * B) break;  // defensive: the device test ends the loop at max_iters
+    }
+    if (s->ev_used) HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = drain_spmv_events(s); if (rc) return rc;
   }
-  s->last_krylov_iters = res.iters;
+  s->last_krylov_iters[use_coarse] = res.iters;
   if (st) { st->iterations = res.iters; st->converged = (res.done == 1); st->residual_norm = std::sqrt(res.rr); st->rhs_norm = bnorm; }
   if (res.done != 1) {
     char buf[160];
@@ -339,7 +359,7 @@ int apply_minv(gmpnp_solver* s, int mode, double* dst, double scale_dst, double 
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   HIP_TRY(hipMemsetAsync(&s->scal.p->done, 0, sizeof(int32_t), s->stream));  // k_coarse honours the flag
   hipLaunchKernelGGL((k_vec_final<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(1), dim3(1024), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
   hipLaunchKernelGGL((k_apply<NF>), dim3(grid_for(s->ndof, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c, dst, scale_dst, scale_x);
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
@@ -372,16 +392,15 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
   bool done = conv(r);
   if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual is NaN before the first Newton iteration");
   while (!done && st.iterations < o.maximum_iterations) {
-    ta = now_ms();
+    HIP_TRY(hipEventRecord(s->ev_phase[0], s->stream));
     rc = launch_element<DIM, NF>(s, true); if (rc) return rc;
     rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc;
     s->jacobian_valid = true;
-    HIP_TRY(hipEventRecord(s->ev_phase[0], s->stream));
-    rc = setup_preconditioner<DIM, NF>(s, o.linear_solver); if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_phase[1], s->stream));
+    rc = setup_preconditioner<DIM, NF>(s, o.linear_solver); if (rc) return rc;
     // rhs = b (current residual vector F)
     HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    const double tk = now_ms();
+    HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
     gmpnp_linear_stats_t ls{};
     rc = krylov<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
                     o.krylov_maximum_iterations, &ls);
@@ -394,15 +413,20 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     }
     // x <- x - omega dx
     rc = apply_minv<NF>(s, o.linear_solver, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
-    const double tk1 = now_ms();
+    HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
     st.iterations++;
-    rc = residual<DIM, NF>(s, false, &r, &flags); if (rc) return rc;
-    const double te = now_ms();
-    float ms_setup = 0.f;
-    (void)hipEventElapsedTime(&ms_setup, s->ev_phase[0], s->ev_phase[1]);
-    st.ms_setup += ms_setup;
-    st.ms_krylov += (tk1 - tk);
-    st.ms_assemble += (tk - ta) - ms_setup + (te - tk1);
+    ta = now_ms();
+    rc = residual<DIM, NF>(s, false, &r, &flags); if (rc) return rc;  // synchronises the stream
+    float ms01 = 0.f, ms12 = 0.f, ms23 = 0.f, ms3 = 0.f;
+    (void)hipEventElapsedTime(&ms01, s->ev_phase[0], s->ev_phase[1]);
+    (void)hipEventElapsedTime(&ms12, s->ev_phase[1], s->ev_phase[2]);
+    (void)hipEventElapsedTime(&ms23, s->ev_phase[2], s->ev_phase[3]);
+    HIP_TRY(hipEventRecord(s->ev_phase[4], s->stream));
+    HIP_TRY(hipEventSynchronize(s->ev_phase[4]));
+    (void)hipEventElapsedTime(&ms3, s->ev_phase[3], s->ev_phase[4]);
+    st.ms_assemble += ms01 + ms3;   // Jacobian assembly + next residual (device time)
+    st.ms_setup += ms12;
+    st.ms_krylov += ms23;
     if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
     if (flags & 6) return fail(GMPNP_ERR_LINEAR, status_message(flags));
     if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
@@ -511,10 +535,11 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->slice_off.upload(t.slice_off)); HIP_TRY(s->slice_colbase.upload(t.slice_colbase));
   HIP_TRY(s->sell_cols.upload(t.sell_cols)); HIP_TRY(s->sell_aggslot.upload(t.sell_aggslot));
   HIP_TRY(s->wl_slice.upload(t.wl_slice)); HIP_TRY(s->wl_kpos.upload(t.wl_kpos));
-  HIP_TRY(s->diag_kpos.upload(t.diag_kpos));
+  HIP_TRY(s->sell_blk.upload(t.sell_blk));
   HIP_TRY(s->Dinv.alloc((size_t)nv * nf * nf));
   HIP_TRY(s->agg.upload(t.agg)); HIP_TRY(s->agg_start.upload(t.agg_start)); HIP_TRY(s->row_aggs.upload(t.row_aggs));
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
+  HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->AciT.alloc((size_t)s->ncoarse * s->ncoarse));
   HIP_TRY(s->vw_node0.upload(t.vw_node0)); HIP_TRY(s->vw_node1.upload(t.vw_node1)); HIP_TRY(s->agg_vw_ptr.upload(t.agg_vw_ptr));
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp, &s->kv, &s->ks, &s->kt, &s->ky, &s->kq, &s->tmpx}) HIP_TRY(b->alloc(ndof));
@@ -522,7 +547,9 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->part_rr.alloc(n_vecwg)); HIP_TRY(s->part_a.alloc(t.nslices)); HIP_TRY(s->part_b.alloc((size_t)4 * t.nslices));
   HIP_TRY(s->part_f.alloc(s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
-  HIP_TRY(hipHostMalloc((void**)&s->h_scal, sizeof(KrylovScalars)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_scal, 2 * sizeof(KrylovScalars)));
+  for (auto& e : s->ev_poll) HIP_TRY(hipEventCreate(&e));
+  if (const char* gi = std::getenv("GMPNP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::atoi(gi));
   HIP_TRY(hipHostMalloc((void**)&s->h_part, std::max(s->n_resblocks, 1) * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
 
@@ -535,17 +562,16 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.rowptr = s->rowptr.p; c.cols = s->cols.p; c.cptr = s->cptr.p; c.contrib = s->contrib.p;
   c.vals = s->vals.p; c.slice_off = s->slice_off.p; c.slice_colbase = s->slice_colbase.p;
   c.sell_cols = s->sell_cols.p; c.sell_aggslot = s->sell_aggslot.p; c.wl_slice = s->wl_slice.p; c.wl_kpos = s->wl_kpos.p;
-  c.diag_kpos = s->diag_kpos.p; c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
-  c.AP = s->AP.p; c.Ac = s->Ac.p; c.AciT = s->AciT.p;
+  c.sell_blk = s->sell_blk.p; c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
+  c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.AciT = s->AciT.p;
   c.vw_node0 = s->vw_node0.p; c.vw_node1 = s->vw_node1.p; c.agg_vw_ptr = s->agg_vw_ptr.p;
   c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp = s->kp.p; c.kv = s->kv.p; c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kq = s->kq.p;
   c.pc_part = s->pc_part.p; c.yc = s->yc.p; c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   // the coarse inverse keeps its whole matrix in LDS: opt in to > 64 KiB of dynamic LDS
-  const int n = s->ncoarse;
-  const size_t lds = (size_t)(n * n + 2 * n + 16) * sizeof(double) + (size_t)(16 + n) * sizeof(int);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (nf == 9) HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds_bytes(s->ncoarse, 9)));
+  else HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds_bytes(s->ncoarse, 7)));
   HIP_TRY(hipDeviceSynchronize());
   *out = s.release();
   return GMPNP_OK;
@@ -660,7 +686,7 @@ int gmpnp_get_jacobian_csr(gmpnp_solver* s, int32_t* indptr, int32_t* indices, d
   for (int vf = 0; vf < t.nv; ++vf) {
     const int I = t.iperm[vf], sl = I / t.S, il = I - sl * t.S;
     order.clear();
-    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) order.push_back({t.perm[t.cols[k]], k - t.rowptr[I]});
+    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) order.push_back({t.perm[t.cols[k]], t.sellk[k]});
     std::sort(order.begin(), order.end());
     for (int i = 0; i < nf; ++i) {
       for (auto& pr : order)

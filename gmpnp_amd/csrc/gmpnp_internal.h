@@ -15,6 +15,7 @@ constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kVecBlock = 256;      // threads per workgroup of the vector kernels
 constexpr int kMaxRowAggs = 4;      // distinct coarse aggregates a block row may touch
 constexpr int kMaxCoarse = 140;     // coarse dimension limit: n^2 doubles must fit the 160 KiB LDS
+constexpr int kCoarseChunks = 32;   // node chunks per aggregate in the Galerkin-product reduction
 constexpr int kSlicePad = 16;       // per-(slice,kpos) column-index record length (>= rows per slice: 7 or 9)
 
 // Device scalars of one BiCGStab solve (one cache line; written by designated lanes, read after a kernel boundary).
@@ -70,17 +71,18 @@ struct Ctx {
   double* vals;
   const int64_t* slice_off;     // [nslices+1] in doubles
   const int32_t* slice_colbase; // [nslices+1]
-  const int32_t* sell_cols;     // [(colbase+kpos)*kSlicePad + Iloc] column node (padding: a valid node)
+  const int32_t* sell_cols;     // [(colbase+kpos)*kSlicePad + Iloc] column node | aggregate << 24 (padding: the row's own node)
+  const int32_t* sell_blk;      // same indexing: BSR block index, -1 = padding
   const uint8_t* sell_aggslot;  // same indexing: slot of the column's aggregate in row_aggs[I] (255 = padding)
   const int32_t* wl_slice;      // [n_work]
   const int32_t* wl_kpos;       // [n_work]
-  const int32_t* diag_kpos;     // [nv]
   // preconditioner
   double* Dinv;                 // [nv][NF][NF]
   const int32_t* agg;           // [nv]
   const int32_t* agg_start;     // [nagg+1] node ranges
   const int32_t* row_aggs;      // [nv][kMaxRowAggs]
   double* AP;                   // [ndof][kMaxRowAggs][NF]
+  double* AcPart;               // [kCoarseChunks][ncoarse][ncoarse] partial sums of Ac
   double* Ac;                   // [ncoarse][ncoarse]
   double* AciT;                 // transposed inverse
   // vector-kernel workgroup table (aggregate- and node-aligned)
@@ -112,10 +114,11 @@ struct Topology {
   std::vector<int32_t> perm, iperm;       // perm[internal] = file ; iperm[file] = internal
   std::vector<double> coords;
   std::vector<int32_t> cells;
-  std::vector<int32_t> rowptr, cols, cptr, contrib, n2e_ptr, n2e, diag_kpos;
+  std::vector<int32_t> rowptr, cols, cptr, contrib, n2e_ptr, n2e;
+  std::vector<int32_t> sellk;      // [nb] position of BSR block k inside its SELL row (diagonal block: 0)
   int nslices = 0;
   std::vector<int64_t> slice_off;
-  std::vector<int32_t> slice_colbase, sell_cols, wl_slice, wl_kpos;
+  std::vector<int32_t> slice_colbase, sell_cols, sell_blk, wl_slice, wl_kpos;
   std::vector<uint8_t> sell_aggslot;
   int nagg = 0;
   std::vector<int32_t> agg, agg_start, row_aggs;

@@ -29,7 +29,8 @@ struct Lay {
   static constexpr int O_IJ = O_EPS + 1;         // [NS] int u_i beta   (J rule)
   static constexpr int O_B = O_IJ + NS;          // [NN] int beta phi_b
   static constexpr int O_C = O_B + NN;           // [NS][NN] int u_i beta^2 phi_b
-  static constexpr int EJ_STRIDE = O_C + NS * NN;
+  static constexpr int O_U = O_C + NS * NN;       // [NN][NS] nodal species values (bilinear reaction derivative)
+  static constexpr int EJ_STRIDE = O_U + NN * NS;
   static constexpr int EF_STRIDE = NN * NF;
   static constexpr double MDEN = 1.0 / ((DIM + 1) * (DIM + 2));  // M_ab = |K| (1+delta_ab) MDEN
   static constexpr double KAPPA = (DIM == 3) ? 1.0 / 120.0 : 1.0 / 24.0;  // d!/(d+3)!
@@ -273,6 +274,10 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
       for (int b = 0; b < NN; ++b) ej[L::O_C + j * NN + b] = Cq[j][b];
     }
     ej[L::O_EPS] = epsbar;
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+#pragma unroll
+      for (int j = 0; j < NS; ++j) ej[L::O_U + a * NS + j] = U[a][j];
   }
 }
 
@@ -323,9 +328,9 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
   if (Iloc >= S) return;
   const int I = s * S + Iloc;
   if (I >= c.nv) return;
-  const int r0 = c.rowptr[I];
-  if (kpos >= c.rowptr[I + 1] - r0) return;  // padding stays zero (set at create)
-  const int k = r0 + kpos, J = c.cols[k];
+  const int k = c.sell_blk[(size_t)(c.slice_colbase[s] + kpos) * kSlicePad + Iloc];
+  if (k < 0) return;  // padding stays zero (set at create)
+  const int J = c.cols[k];
   double* out = c.vals + c.slice_off[s] + (size_t)kpos * NF * kWave + lane;
   if (c.bcflag[I * NF + i]) {  // [3P] DirichletBC.apply(A): identity row
 #pragma unroll
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
 #pragma unroll
   for (int j = 0; j < NF; ++j) acc[j] = 0.0;
 
+#pragma unroll 4
   for (int q = c.cptr[k]; q < c.cptr[k + 1]; ++q) {
     const int pk = c.contrib[q];
     const int e = pk >> 4, a = (pk >> 2) & 3, b = pk & 3;
@@ -359,9 +365,8 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
         const double c2 = m.rc2[is][t];
         if (c2 != 0.0) {
           const int bj = m.bil_j[t], bk = m.bil_k[t];
-          const int na = c.cells[e * NN + a], nb_ = c.cells[e * NN + b];
-          const double xa = c.u[(size_t)na * NF + bj], xb = c.u[(size_t)nb_ * NF + bj];
-          const double ya = c.u[(size_t)na * NF + bk], yb = c.u[(size_t)nb_ * NF + bk];
+          const double xa = ej[L::O_U + a * NS + bj], xb = ej[L::O_U + b * NS + bj];
+          const double ya = ej[L::O_U + a * NS + bk], yb = ej[L::O_U + b * NS + bk];
           const double Xs = NN * ej[L::O_UBAR + bj], Ys = NN * ej[L::O_UBAR + bk];
           const double w = c2 * vol * L::KAPPA;
           const double dj = w * (Ys + ya + yb + (a == b ? Ys + 2.0 * ya : 0.0));  // d/d u_{bj,b}
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(64) void k_block_inverse(const Ctx c) {
   const int I = blockIdx.x * 64 + threadIdx.x, t = threadIdx.x;
   if (I >= c.nv) return;
   const int s = I / S, Iloc = I - s * S;
-  const double* base = c.vals + c.slice_off[s] + (size_t)c.diag_kpos[I] * NF * kWave + Iloc * NF;
+  const double* base = c.vals + c.slice_off[s] + Iloc * NF;  // the diagonal block is SELL position 0
   for (int i = 0; i < NF; ++i)
     for (int j = 0; j < NF; ++j) A[i * NF + j][t] = base[(size_t)j * kWave + i];
   int piv[NF];
@@ -469,90 +474,158 @@ __global__ __launch_bounds__(64) void k_coarse_rows(const Ctx c) {
 
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_coarse_sum(const Ctx c) {
-  const int g = blockIdx.x, n = c.ncoarse;
+  // workgroup (g, chunk): partial sums over one chunk of the nodes of aggregate g
+  const int g = blockIdx.x / kCoarseChunks, ch = blockIdx.x - g * kCoarseChunks, n = c.ncoarse;
+  const int a0 = c.agg_start[g], len = c.agg_start[g + 1] - a0;
+  const int I0 = a0 + (int)((int64_t)len * ch / kCoarseChunks), I1 = a0 + (int)((int64_t)len * (ch + 1) / kCoarseChunks);
+  double* out = c.AcPart + ((size_t)ch * n + (size_t)g * NF) * n;
   for (int idx = threadIdx.x; idx < NF * n; idx += kVecBlock) {
     const int i = idx / n, col = idx - i * n, h = col / NF, j = col - h * NF;
     double s = 0.0;
-    for (int I = c.agg_start[g]; I < c.agg_start[g + 1]; ++I) {
+    for (int I = I0; I < I1; ++I) {
       const int32_t* ra = c.row_aggs + (size_t)I * kMaxRowAggs;
 #pragma unroll
       for (int q = 0; q < kMaxRowAggs; ++q)
         if (ra[q] == h) s += c.AP[((size_t)(I * NF + i) * kMaxRowAggs + q) * NF + j];
     }
-    c.Ac[(size_t)(g * NF + i) * n + col] = s;
+    out[(size_t)i * n + col] = s;
   }
 }
 
-// In-place Gauss-Jordan inverse of the coarse operator by one 1024-thread workgroup, matrix resident in LDS.
-__global__ __launch_bounds__(1024) void k_coarse_invert(const Ctx c) {
+__global__ __launch_bounds__(kVecBlock) void k_coarse_reduce(const Ctx c) {
+  const int n2 = c.ncoarse * c.ncoarse, q = blockIdx.x * kVecBlock + threadIdx.x;
+  if (q >= n2) return;
+  double s = 0.0;
+  for (int ch = 0; ch < kCoarseChunks; ++ch) s += c.AcPart[(size_t)ch * n2 + q];
+  c.Ac[q] = s;
+}
+
+// In-place BLOCK Gauss-Jordan inverse of the coarse operator (block = one aggregate, NF x NF) by one
+// 512-thread workgroup with the whole matrix resident in LDS.  Pivoting happens inside the diagonal
+// block only (its inverse is formed by NF lanes with partial pivoting); the off-diagonal update is a
+// rank-NF update done in 3x3 register tiles.
+template <int NF>
+__global__ __launch_bounds__(512) void k_coarse_invert(const Ctx c) {
   extern __shared__ double sm[];
-  const int n = c.ncoarse, t = threadIdx.x, nt = blockDim.x;
-  double* A = sm;               // n*n
-  double* rowk = A + n * n;     // n
-  double* colk = rowk + n;      // n
-  double* redv = colk + n;      // 16
-  int* redi = (int*)(redv + 16);   // 16
-  int* piv = redi + 16;         // n
+  const int n = c.ncoarse, nblk = n / NF, t = threadIdx.x, nt = blockDim.x;
+  double* A = sm;                 // n*n
+  double* colK = A + n * n;       // n*NF : old column block K
+  double* D = colK + n * NF;      // NF*(2*NF) augmented [A_KK | I] -> [I | inv]
   __shared__ int sing;
   if (t == 0) sing = 0;
   for (int q = t; q < n * n; q += nt) A[q] = c.Ac[q];
   __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    // pivot search in column k, rows k..n-1 (n <= 192: three waves hold one candidate each lane)
-    double v = -1.0; int idx = k;
-    if (t < 192) { const int r = t; if (r >= k && r < n) { v = fabs(A[r * n + k]); idx = r; } }
-    if (t < 192) {
+  const int ntile = (n + 2) / 3;
+  for (int K = 0; K < nblk; ++K) {
+    const int k0 = K * NF;
+    // (1) D = inverse of the diagonal block: lanes 0..NF-1 of wave 0 own one row each
+    if (t < 64) {
+      const int r = t;
+      double row[2 * NF];
+      if (r < NF) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o, 64); const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        for (int j = 0; j < NF; ++j) { row[j] = A[(k0 + r) * n + k0 + j]; row[NF + j] = (j == r) ? 1.0 : 0.0; }
       }
-      if ((t & 63) == 0) { redv[t >> 6] = v; redi[t >> 6] = idx; }
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        // pivot row among lanes k..NF-1
+        double v = (r < NF && r >= k) ? fabs(row[k]) : -1.0; int idx = r;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          const double ov = __shfl_xor(v, o, 16); const int oi = __shfl_xor(idx, o, 16);
+          if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        bad |= !(v > 0.0);
+        // rows k and idx swap places (lane k takes the pivot row, lane idx the old row k), then scale / eliminate
+        const double ip = 1.0 / __shfl(row[k], idx, 16);
+        const double oldk_k = __shfl(row[k], k, 16);
+        const double f = ((r == idx) ? oldk_k : row[k]) * ip;
+#pragma unroll
+        for (int j = 0; j < 2 * NF; ++j) {
+          const double from_p = __shfl(row[j], idx, 16), from_k = __shfl(row[j], k, 16);
+          const double mine = (r == idx) ? from_k : row[j];
+          row[j] = (r == k) ? from_p * ip : mine - f * from_p;
+        }
+      }
+      if (r < NF) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) D[r * NF + j] = row[NF + j];
+      }
+      if (bad && t == 0) sing = 1;
     }
-    __syncthreads();
-    if (t == 0) {
-      double bv = redv[0]; int bi = redi[0];
-      for (int w = 1; w < 3; ++w) if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
-      piv[k] = bi;
-      if (!(bv > 0.0)) sing = 1;
-    }
+    // (2a) save the old column block K
+    for (int q = t; q < n * NF; q += nt) { const int r = q / NF, m = q - r * NF; colK[q] = A[r * n + k0 + m]; }
     __syncthreads();
     if (sing) break;
-    const int p = piv[k];
-    if (p != k && t < n) { const double tmp = A[k * n + t]; A[k * n + t] = A[p * n + t]; A[p * n + t] = tmp; }
+    // (2b) row block K: A[K,K] = D ; A[K,c] = D * A[K,c]   (column-wise, each thread one column)
+    for (int cc = t; cc < n; cc += nt) {
+      double colv[NF];
+      const bool inK = (cc >= k0 && cc < k0 + NF);
+#pragma unroll
+      for (int m = 0; m < NF; ++m) colv[m] = A[(k0 + m) * n + cc];
+#pragma unroll
+      for (int r = 0; r < NF; ++r) {
+        double sacc = 0.0;
+        if (inK) sacc = D[r * NF + (cc - k0)];
+        else
+#pragma unroll
+          for (int m = 0; m < NF; ++m) sacc += D[r * NF + m] * colv[m];
+        A[(k0 + r) * n + cc] = sacc;
+      }
+    }
     __syncthreads();
-    const double ip = 1.0 / A[k * n + k];
-    if (t < n) colk[t] = A[t * n + k];
-    __syncthreads();
-    if (t < n) rowk[t] = (t == k) ? ip : A[k * n + t] * ip;
-    __syncthreads();
-    for (int q = t; q < n * n; q += nt) {
-      const int r = q / n, cc = q - r * n;
-      if (r == k) A[q] = rowk[cc];
-      else A[q] = ((cc == k) ? 0.0 : A[q]) - colk[r] * rowk[cc];
+    // (3) other row blocks: A[r][c] = (c in K ? 0 : A[r][c]) - sum_m colK[r][m] * A[K*NF+m][c]
+    for (int tile = t; tile < ntile * ntile; tile += nt) {
+      const int tr = tile / ntile, tc = tile - tr * ntile;
+      const int r0 = 3 * tr, c0 = 3 * tc;
+      double acc[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) acc[a][b2] = 0.0;
+#pragma unroll
+      for (int m = 0; m < NF; ++m) {
+        double cv[3], wv[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) cv[a] = (r0 + a < n) ? colK[(r0 + a) * NF + m] : 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) wv[b2] = (c0 + b2 < n) ? A[(k0 + m) * n + c0 + b2] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) acc[a][b2] += cv[a] * wv[b2];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int r = r0 + a;
+        if (r >= n || (r >= k0 && r < k0 + NF)) continue;
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+          const int cc = c0 + b2;
+          if (cc >= n) continue;
+          const bool inK = (cc >= k0 && cc < k0 + NF);
+          A[r * n + cc] = (inK ? 0.0 : A[r * n + cc]) - acc[a][b2];
+        }
+      }
     }
     __syncthreads();
   }
   if (sing) { if (t == 0) atomicOr(c.status, 4); return; }
-  for (int k = n - 1; k >= 0; --k) {
-    const int p = piv[k];
-    if (p != k && t < n) { const double tmp = A[t * n + k]; A[t * n + k] = A[t * n + p]; A[t * n + p] = tmp; }
-    __syncthreads();
-  }
-  for (int q = t; q < n * n; q += nt) { const int r = q / n, cc = q - r * n; c.AciT[(size_t)cc * n + r] = A[q]; }
+  for (int q = t; q < n * n; q += nt) c.AciT[q] = A[q];  // row-major inverse (name kept: see k_coarse)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Coarse solve: pc = sum of the restriction partials of each aggregate (fixed order), yc = Aci pc.
-// One workgroup; thread (row, chunk) with 4 column chunks.
+// Coarse solve yc = Aci pc, one wave per coarse row (4 rows per workgroup); pc = sum of the restriction
+// partials of each aggregate in a fixed order, rebuilt in LDS by every workgroup (a few KB from L2).
 // ---------------------------------------------------------------------------------------------
 template <int NF>
-__global__ __launch_bounds__(1024) void k_coarse(const Ctx c, int use_coarse) {
+__global__ __launch_bounds__(kVecBlock) void k_coarse(const Ctx c, int use_coarse) {
   __shared__ double pc[kMaxCoarse];
-  __shared__ double red[4][kMaxCoarse];
   if (c.scal->done) return;
   const int n = c.ncoarse, t = threadIdx.x;
-  if (!use_coarse) { if (t < n) c.yc[t] = 0.0; return; }
+  const int row = blockIdx.x * 4 + (t >> 6), lane = t & 63;
+  if (!use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
   if (t < n) {
     const int g = t / NF, f = t - g * NF;
     double s = 0.0;
@@ -560,15 +633,11 @@ __global__ __launch_bounds__(1024) void k_coarse(const Ctx c, int use_coarse) {
     pc[t] = s;
   }
   __syncthreads();
-  const int row = t % kMaxCoarse, ch = t / kMaxCoarse;  // 1024 threads -> 7 chunks available, use 4
-  if (ch < 4 && row < n) {
-    const int c0 = (n * ch) / 4, c1 = (n * (ch + 1)) / 4;
-    double s = 0.0;
-    for (int cc = c0; cc < c1; ++cc) s += c.AciT[(size_t)cc * n + row] * pc[cc];
-    red[ch][row] = s;
-  }
-  __syncthreads();
-  if (t < n) c.yc[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  if (row >= n) return;
+  double s = 0.0;
+  for (int cc = lane; cc < n; cc += 64) s += c.AciT[(size_t)row * n + cc] * pc[cc];
+  s = wave_sum(s);
+  if (lane == 0) c.yc[row] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,9 +659,9 @@ __global__ __launch_bounds__(kVecBlock) void k_spmv(const Ctx c, const double* _
     const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
     const double* base = c.vals + c.slice_off[s] + lane;
     for (int kp = w; kp < mx; kp += 4) {
-      const int col = c.sell_cols[(size_t)(cb + kp) * kSlicePad + Iloc];
-      const double* xv = x + (size_t)col * NF;
-      const double* yv = c.yc + c.agg[col] * NF;
+      const int pk = c.sell_cols[(size_t)(cb + kp) * kSlicePad + Iloc];
+      const double* xv = x + (size_t)(pk & 0xFFFFFF) * NF;
+      const double* yv = c.yc + (pk >> 24) * NF;
       const double* av = base + (size_t)kp * NF * kWave;
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc += av[(size_t)j * kWave] * (xv[j] + yv[j]);

@@ -54,8 +54,6 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
     const int32_t* b = t.cols.data() + t.rowptr[I]; const int32_t* e = t.cols.data() + t.rowptr[I + 1];
     return (int)(std::lower_bound(b, e, J) - t.cols.data());
   };
-  t.diag_kpos.resize(nv);
-  for (int i = 0; i < nv; ++i) t.diag_kpos[i] = find_block(i, i) - t.rowptr[i];
 
   // ---- contributions per block (element order => deterministic summation) ---------------------
   t.cptr.assign(nb + 1, 0);
@@ -84,7 +82,8 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
       for (int a = 0; a < nn; ++a) t.n2e[fill[t.cells[(size_t)e * nn + a]]++] = e * nn + a; }
 
   // ---- aggregates: contiguous, equal-count ranges of the internal order -------------------------
-  int nagg_max = kMaxCoarse / nf;
+  int nagg_max = kMaxCoarse / nf;  // and the LDS-resident block Gauss-Jordan must fit in 160 KiB
+  while (nagg_max > 1 && (size_t)((nagg_max * nf) * (nagg_max * nf) + nagg_max * nf * nf + 2 * nf * nf) * sizeof(double) > 160u * 1024u) --nagg_max;
   int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : nagg_max;
   nagg = std::max(1, std::min(nagg, nv / 8 > 0 ? nv / 8 : 1));
   for (;; --nagg) {  // shrink until no row touches more than kMaxRowAggs aggregates
@@ -107,6 +106,21 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   nagg = t.nagg;
 
   // ---- SELL slices ------------------------------------------------------------------------------
+  // Inside a row the blocks may sit in any order: put the diagonal first and the others by decreasing
+  // number of element contributions, so the rows of one slice present the gather kernel with similar work.
+  if (nv >= (1 << 24)) return "mesh too large for the packed (column, aggregate) index";
+  t.sellk.resize(nb);
+  { std::vector<int> ord;
+    for (int I = 0; I < nv; ++I) {
+      ord.clear();
+      for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) ord.push_back(k);
+      std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+        const bool dx = t.cols[x] == I, dy = t.cols[y] == I;
+        if (dx != dy) return dx;
+        return (t.cptr[x + 1] - t.cptr[x]) > (t.cptr[y + 1] - t.cptr[y]);
+      });
+      for (size_t q = 0; q < ord.size(); ++q) t.sellk[ord[q]] = (int32_t)q;
+    } }
   const int S = t.S;
   t.nslices = (nv + S - 1) / S;
   t.slice_off.assign(t.nslices + 1, 0); t.slice_colbase.assign(t.nslices + 1, 0);
@@ -115,24 +129,29 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
     for (int I = s * S; I < std::min(nv, (s + 1) * S); ++I) mx = std::max(mx, t.rowptr[I + 1] - t.rowptr[I]);
     t.slice_colbase[s + 1] = t.slice_colbase[s] + mx;
     t.slice_off[s + 1] = t.slice_off[s] + (int64_t)mx * nf * kWave;
-    for (int kp = 0; kp < mx; ++kp) { t.wl_slice.push_back(s); t.wl_kpos.push_back(kp); }
   }
+  // gather work list, heaviest SELL positions (diagonal blocks) first
+  { int mxall = 0;
+    for (int s = 0; s < t.nslices; ++s) mxall = std::max(mxall, t.slice_colbase[s + 1] - t.slice_colbase[s]);
+    for (int kp = 0; kp < mxall; ++kp)
+      for (int s = 0; s < t.nslices; ++s)
+        if (kp < t.slice_colbase[s + 1] - t.slice_colbase[s]) { t.wl_slice.push_back(s); t.wl_kpos.push_back(kp); } }
   const int ncolrec = t.slice_colbase[t.nslices];
   t.sell_cols.assign((size_t)ncolrec * kSlicePad, 0); t.sell_aggslot.assign((size_t)ncolrec * kSlicePad, 255);
-  for (int s = 0; s < t.nslices; ++s) {
-    int mx = t.slice_colbase[s + 1] - t.slice_colbase[s];
-    for (int kp = 0; kp < mx; ++kp)
-      for (int il = 0; il < S; ++il) {
-        int I = s * S + il; size_t rec = ((size_t)t.slice_colbase[s] + kp) * kSlicePad + il;
-        if (I >= nv) { t.sell_cols[rec] = 0; continue; }
-        if (kp < t.rowptr[I + 1] - t.rowptr[I]) {
-          int J = t.cols[t.rowptr[I] + kp]; t.sell_cols[rec] = J;
-          for (int q = 0; q < kMaxRowAggs; ++q)
-            if (t.row_aggs[(size_t)I * kMaxRowAggs + q] == t.agg[J]) t.sell_aggslot[rec] = (uint8_t)q;
-        } else {
-          t.sell_cols[rec] = I;  // padding: value is zero, index stays valid
-        }
-      }
+  t.sell_blk.assign((size_t)ncolrec * kSlicePad, -1);
+  for (int I = 0; I < nv; ++I) {
+    const int s = I / S, il = I - s * S;
+    const int mx = t.slice_colbase[s + 1] - t.slice_colbase[s];
+    for (int kp = 0; kp < mx; ++kp)  // padding: value stays zero, the index stays valid
+      t.sell_cols[((size_t)t.slice_colbase[s] + kp) * kSlicePad + il] = I | (t.agg[I] << 24);
+    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) {
+      const size_t rec = ((size_t)t.slice_colbase[s] + t.sellk[k]) * kSlicePad + il;
+      const int J = t.cols[k];
+      t.sell_cols[rec] = J | (t.agg[J] << 24);
+      t.sell_blk[rec] = k;
+      for (int q = 0; q < kMaxRowAggs; ++q)
+        if (t.row_aggs[(size_t)I * kMaxRowAggs + q] == t.agg[J]) t.sell_aggslot[rec] = (uint8_t)q;
+    }
   }
 
   // ---- vector-kernel workgroups: whole nodes, one aggregate each --------------------------------

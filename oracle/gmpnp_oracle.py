@@ -343,3 +343,70 @@ def project_gradient(coords, cells, f, sign=1.0):
         rhs = np.bincount(cells.ravel(), weights=np.repeat(sign * gradf[:, k] * vol * i1, nn), minlength=nv)
         out[:, k] = lu.solve(rhs)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Time loops (reference 3D:783-858 and 1D:633-796), oracle-side restatement for golden vectors
+# ---------------------------------------------------------------------------------------------
+def pore_time_loop(pp, prob, bnd, n_steps, newton_kwargs=None, verbose=False):
+    """Backward-Euler loop of the 3D pore driver: Newton from the previous u (zeros at step 0, SURVEY §3.3
+    item 6), median -> Sechenov -> new CO2 Dirichlet value (3D:817-838), u_n.assign(u) (3D:856).
+    Returns dict(states (n_steps, ndof), newton_its, residuals, co2_bc)."""
+    from gmpnp_amd.problem import pore_dirichlet
+    kw = dict(maximum_iterations=50, relative_tolerance=1e-4, absolute_tolerance=1e-4, relaxation_parameter=0.9)
+    kw.update(newton_kwargs or {})
+    nv, nf = prob.coords.shape[0], prob.nf
+    u = np.zeros(prob.ndof)
+    un = np.tile(np.r_[np.ones(nf - 1), 0.0], nv)
+    out = {"states": [], "newton_its": [], "residuals": [], "co2_bc": []}
+    for n in range(n_steps):
+        u, st = newton_solve(prob, u, un, **kw)
+        u2 = u.reshape(nv, nf)
+        co2 = pp.sechenov_co2_scaled(np.median(u2[:, 1]), np.median(u2[:, 2]), np.median(u2[:, 3]), np.median(u2[:, 7]))
+        prob.bc_dofs, prob.bc_vals = pore_dirichlet(pp, bnd, co2)
+        un = u.copy()
+        out["states"].append(u.copy()); out["newton_its"].append(st.iterations)
+        out["residuals"].append(list(st.residuals)); out["co2_bc"].append(co2)
+        if verbose:
+            print("step", n, "its", st.iterations, "res", st.residuals[-1], "co2", co2, flush=True)
+    out["states"] = np.array(out["states"])
+    return out
+
+
+def edl_time_loop(ep, prob, n_steps, newton_kwargs=None, verbose=False):
+    """Dry-run loop of the 1D EDL driver (1D:633-796) without stabilisation: Newton (omega = 1), optional
+    proton-flux controller (1D:766-793), u_n.assign(u)."""
+    import copy
+    kw = dict(maximum_iterations=50, relative_tolerance=1e-4, absolute_tolerance=1e-4, relaxation_parameter=1.0)
+    kw.update(newton_kwargs or {})
+    nv, nf = prob.coords.shape[0], prob.nf
+    u = np.zeros(prob.ndof)
+    un = np.tile(np.r_[np.ones(nf - 1), 0.0], nv)
+    frac = ep.current_H_frac
+    out = {"states": [], "newton_its": [], "residuals": [], "current_H_frac": []}
+    prob.model = copy.deepcopy(prob.model)
+    iH, iOH = ep.species.index("H"), ep.species.index("OH")
+    for n in range(n_steps):
+        u, st = newton_solve(prob, u, un, **kw)
+        f = u.reshape(nv, nf)[0, iH]
+        if ep.H_OHP is not None:
+            H = ep.H_OHP
+            if f < 0:
+                frac = frac / 1.1
+            elif f < (H - 0.05):
+                frac = frac / 1.05
+            elif f < (H - 0.025):
+                frac = frac / 1.01
+            elif (f > H and f <= (H + 0.4) and frac <= 1.0):
+                frac = frac * 1.04
+            elif f > (H + 0.4) and frac <= 1.0:
+                frac = frac * 1.15
+            JH, JOH = ep.ohp_fluxes(frac)
+            prob.model.point_flux[iH], prob.model.point_flux[iOH] = JH, JOH
+        un = u.copy()
+        out["states"].append(u.copy()); out["newton_its"].append(st.iterations)
+        out["residuals"].append(list(st.residuals)); out["current_H_frac"].append(frac)
+        if verbose:
+            print("step", n, "its", st.iterations, "res", st.residuals[-1], flush=True)
+    out["states"] = np.array(out["states"])
+    return out

@@ -48,3 +48,5 @@ for rep in range(3):
     print("newton its %d krylov %s  %.4fs  -> %.1f its/s ; ms asm %.2f setup %.2f krylov %.2f" % (st["iterations"], st["krylov_per_iteration"], dt, st["iterations"] / dt, st["ms_assemble"], st["ms_setup"], st["ms_krylov"]))
 print("residuals", st["residuals"])
 np.save(os.path.join(ROOT, "gpurun_out", "u_step1_gpu.npy"), dev.get_state())
+for rep in range(3):
+    t = time.time(); xs, st = dev.linear_solve(Fo, backend.LINEAR_TWOLEVEL, 1e-10, 0.0, 5000); print("twolevel again", st["iterations"], "%.3f ms" % (1e3 * (time.time() - t)))
