@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference's operator API for the hot path: ``solve(F == 0, u, bcs, solver_parameters)``
+(reference 3D/MPNP_CO2ER_pore.py:789-799, 1D/MPNP_CO2ER_EDL.py:737-742) and the per-step glue around it
+(``u_n.assign(u)``, ``compute_vertex_values``, Dirichlet rebuilds).  All arithmetic happens in libgmpnp.so."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import backend
+from .problem import Problem
+
+
+class GMPNPSystem:
+    """The objects a reference script holds between ``FunctionSpace`` and the time loop: mesh, forms (model tables),
+    ``u``/``u_n`` (device resident) and the ``bcs`` list."""
+
+    def __init__(self, problem: Problem, **device_kwargs):
+        self.problem = problem
+        self.dev = backend.DeviceSolver(problem, **device_kwargs)
+        self.nv = problem.coords.shape[0]
+        self.nf = problem.nf
+        self.newton_iterations = 0
+        self.krylov_iterations = 0
+        self.last_stats = None
+
+    # u = Function(V) is zero-initialised; u_n = interpolate(u_0, V)  (3D:425-432, 1D:320-326)
+    def initialise(self, u0_values):
+        u_n = np.tile(np.asarray(u0_values, dtype=np.float64), self.nv)
+        self.dev.set_state(np.zeros(self.problem.ndof), u_n)
+
+    def set_bcs(self, dofs, vals):
+        self.problem.bc_dofs, self.problem.bc_vals = dofs, vals
+        self.dev.set_dirichlet(dofs, vals)
+
+    def set_model(self, model):
+        self.problem.model = model
+        self.dev.set_model(model)
+
+    def solve(self, solver_parameters=None):
+        """``solve(F == 0, u, bcs, solver_parameters=...)``.  RuntimeError on non-convergence, as DOLFIN."""
+        opts = backend.newton_options(solver_parameters)
+        try:
+            st = self.dev.newton_solve(opts)
+        except backend.GmpnpError as e:
+            if e.code == backend.ERR_NOT_CONVERGED:
+                raise RuntimeError("Newton solver did not converge because maximum number of iterations reached") from e
+            raise
+        self.newton_iterations += st["iterations"]
+        self.krylov_iterations += st["krylov_iterations"]
+        self.last_stats = st
+        return st
+
+    def vertex_values(self):
+        """(nv, nf) array = compute_vertex_values() of every sub-function, file vertex order."""
+        return self.dev.get_state().reshape(self.nv, self.nf)
+
+    def assign_previous(self):
+        self.dev.assign_previous()
+
+    def close(self):
+        self.dev.close()
+
+
+def project_gradient(coords, cells, f, sign=1.0):
+    """``project(sign*grad(f), W).compute_vertex_values()`` for a P1 field (reference 1D:802-805, 3D:884-909):
+    consistent-mass L2 projection of the cell-wise constant gradient.  Post-processing, run once
+    after the time loop on the host with SciPy's sparse LU — it is not part of the hot path.  Returns (nv, d)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    nv, d = coords.shape
+    nn = d + 1
+    X = coords[cells]
+    if d == 1:
+        h = X[:, 1, 0] - X[:, 0, 0]
+        vol = np.abs(h)
+        g = np.zeros((len(cells), 2, 1))
+        g[:, 0, 0], g[:, 1, 0] = -1.0 / h, 1.0 / h
+    else:
+        T = X[:, 1:, :] - X[:, :1, :]
+        Tinv = np.linalg.inv(T)
+        g = np.empty((len(cells), 4, 3))
+        g[:, 1:, :] = np.transpose(Tinv, (0, 2, 1))
+        g[:, 0, :] = -g[:, 1:, :].sum(axis=1)
+        vol = np.abs(np.linalg.det(T)) / 6.0
+    M = (np.ones((nn, nn)) + np.eye(nn)) / ((d + 1) * (d + 2))
+    rows = np.repeat(cells, nn, axis=1).ravel()
+    cols = np.tile(cells, (1, nn)).ravel()
+    Mg = sp.coo_matrix(((M[None] * vol[:, None, None]).ravel(), (rows, cols)), shape=(nv, nv)).tocsc()
+    lu = spla.splu(Mg)
+    gradf = np.einsum("ea,ead->ed", f[cells], g)
+    out = np.empty((nv, d))
+    for k in range(d):
+        rhs = np.bincount(cells.ravel(), weights=np.repeat(sign * gradf[:, k] * vol / nn, nn), minlength=nv)
+        out[:, k] = lu.solve(rhs)
+    return out

@@ -1,0 +1,287 @@
+"""GPU parity tests: every call goes through the C-ABI of libgmpnp.so (gmpnp_amd.backend) and is compared with the
+CPU oracle on the same seeded inputs, or with the committed golden vectors (tests/golden) at full size.
+
+Stated tolerances (fp64 everywhere):
+  assembly / SpMV vs oracle ................ 1e-12 relative (different summation order only)
+  linear solve vs sparse LU ................ 1e-8  relative (BiCGStab at 1e-10 relative residual)
+  Newton iterates / time steps vs oracle ... 1e-8  relative, identical Newton iteration counts
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+import gmpnp_oracle as O
+from conftest import GOLDEN, random_state
+
+pytestmark = pytest.mark.gpu
+
+MUMPS_09 = {"nonlinear_solver": "newton", "newton_solver": {
+    "linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-4, "absolute_tolerance": 1e-4,
+    "relaxation_parameter": 0.9}}
+DEFAULT_1D = {"nonlinear_solver": "newton", "newton_solver": {
+    "maximum_iterations": 50, "relative_tolerance": 1e-4, "absolute_tolerance": 1e-4}}
+
+
+def relerr(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def frob_rel(A, B):
+    D = (A - B).tocsr()
+    return np.sqrt((D.data ** 2).sum()) / np.sqrt((B.data ** 2).sum())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["pore10", "pore50", "edl1", "edl50"])
+def test_assembly_matches_oracle(case, request, gpu_lib):
+    fx = request.getfixturevalue(case)
+    prob = fx[2]
+    nv, ns = prob.coords.shape[0], prob.nf - 1
+    u, un = random_state(nv, ns, seed=3)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        F, nrm = dev.assemble(True)
+        A = dev.jacobian_csr()
+        # a second assembly is bitwise reproducible (gather assembly, no atomics)
+        F2, _ = dev.assemble(True)
+        assert np.array_equal(F, F2) and np.array_equal(A.data, dev.jacobian_csr().data)
+    Fo, Ao = O.assemble(prob, u, un)
+    assert relerr(F, Fo) < 1e-12
+    assert abs(nrm - np.linalg.norm(Fo)) / np.linalg.norm(Fo) < 1e-12
+    assert A.nnz == Ao.nnz and np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices)
+    assert frob_rel(A, Ao) < 1e-12
+    d = prob.bc_dofs
+    assert np.array_equal(F[d], u[d] - prob.bc_vals)  # b = x - g exactly
+    assert np.all(A.diagonal()[d] == 1.0) and abs(A[d]).sum() == len(d)  # identity rows exactly
+
+
+def test_assembly_as_published_variant(pore10, gpu_lib):
+    """without the ds(2)/ds(3) terms (what the published script assembles)."""
+    from gmpnp_amd.params import pore_parameters
+    from gmpnp_amd.problem import pore_problem
+    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9, as_published=True)
+    prob, _ = pore_problem(pp, pore10[1])
+    u, un = random_state(prob.coords.shape[0], 8, seed=4)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        F, _ = dev.assemble(True)
+        A = dev.jacobian_csr()
+    Fo, Ao = O.assemble(prob, u, un)
+    assert relerr(F, Fo) < 1e-12 and frob_rel(A, Ao) < 1e-12
+    Fi, _ = O.assemble(pore10[2], u, un)
+    assert relerr(Fo, Fi) > 1e-6  # the flux terms do matter
+
+
+def test_steric_guard_reports_instead_of_nan(pore10, gpu_lib):
+    prob = pore10[2]
+    u, un = random_state(prob.coords.shape[0], 8)
+    u = u.reshape(-1, 9)
+    u[:, 7] = 40.0  # sum_j a_j u_j > 1 everywhere
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u.ravel(), un)
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.assemble(True)
+        assert ei.value.code == gpu_lib.ERR_NUMERIC
+
+
+@pytest.mark.parametrize("case", ["pore10", "edl1"])
+def test_spmv_and_linear_solve(case, request, gpu_lib):
+    prob = request.getfixturevalue(case)[2]
+    nv, ns = prob.coords.shape[0], prob.nf - 1
+    u, un = random_state(nv, ns, seed=5)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(prob.ndof)
+    Fo, Ao = O.assemble(prob, u, un)
+    xo = spla.splu(Ao.tocsc()).solve(Fo)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.assemble(True)
+        assert relerr(dev.spmv(x), Ao @ x) < 1e-13
+        # linearity of the device operator
+        y1, y2 = dev.spmv(x), dev.spmv(2.5 * x)
+        assert relerr(y2, 2.5 * y1) < 1e-15
+        xs, st = dev.linear_solve(Fo, gpu_lib.LINEAR_TWOLEVEL, 1e-10, 0.0, 5000)
+        assert st["converged"] and relerr(Ao @ xs, Fo) < 2e-10
+        assert relerr(xs, xo) < 1e-8 if case == "pore10" else relerr(Ao @ xs, Fo) < 2e-10
+        if case == "pore10":
+            xj, stj = dev.linear_solve(Fo, gpu_lib.LINEAR_JACOBI, 1e-10, 0.0, 20000)
+            assert stj["converged"] and relerr(xj, xo) < 1e-8
+            assert stj["iterations"] > 3 * st["iterations"]  # the coarse correction pays
+        # zero right-hand side
+        xz, stz = dev.linear_solve(np.zeros(prob.ndof), gpu_lib.LINEAR_TWOLEVEL, 1e-10, 0.0, 100)
+        assert not xz.any() and stz["iterations"] == 0
+        # iteration limit reached -> status, not garbage
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.linear_solve(Fo, gpu_lib.LINEAR_JACOBI, 1e-14, 0.0, 3)
+        assert ei.value.code == gpu_lib.ERR_LINEAR
+
+
+def test_newton_first_step_matches_oracle(pore10, gpu_lib):
+    pp, mesh, prob, bnd = pore10
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    nv = mesh.num_vertices
+    u0, un = np.zeros(prob.ndof), np.tile(np.r_[np.ones(8), 0.0], nv)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u0, un)
+        st = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        u = dev.get_state()
+        # converged state: the convergence test runs before the first iteration -> 0 Newton iterations
+        st0 = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        assert st0["iterations"] == 0 and st0["converged"] and np.array_equal(dev.get_state(), u)
+    assert st["iterations"] == int(g["newton_its"][0]) == 7
+    ref = g["residuals"][0][:8]
+    assert np.allclose(st["residuals"], ref, rtol=1e-7)
+    assert relerr(u, g["states"][0]) < 1e-8
+    assert abs(st["residuals"][0] - ref[0]) / ref[0] < 1e-13  # ||b0|| is dominated by the bc rows (~1.2e3)
+
+
+def test_newton_nonconvergence_is_an_error(pore10, gpu_lib):
+    prob = pore10[2]
+    nv = prob.coords.shape[0]
+    sp = copy.deepcopy(MUMPS_09)
+    sp["newton_solver"]["maximum_iterations"] = 2
+    from gmpnp_amd.solver import GMPNPSystem
+    s = GMPNPSystem(prob)
+    try:
+        s.initialise([1.0] * 8 + [0.0])
+        with pytest.raises(RuntimeError, match="did not converge"):
+            s.solve(sp)
+        st = s.dev.newton_solve(gpu_lib.newton_options(sp), error_on_nonconvergence=False)
+        assert st["iterations"] == 2 and not st["converged"]
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("case,nsteps", [("pore10", 3), ("pore50", 2)])
+def test_pore_time_loop_matches_golden(case, nsteps, gpu_lib):
+    """The driver's loop (Newton, median -> Sechenov -> new bc4, u_n.assign(u)) against the oracle's golden steps."""
+    from gmpnp_amd.pore3d import PoreRun
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    _, L, R = g["args"]
+    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=float(L), R=float(R))
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        for k in range(nsteps):
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
+        co2 = run.problem.bc_vals[np.searchsorted(run.problem.bc_dofs, run.bnd.dirichlet_vertices[1][0] * 9 + 4)]
+        assert abs(co2 - g["co2_bc"][nsteps - 1]) / co2 < 1e-9
+        assert run.history[0][:, :8].min() == 1.0 and not run.history[0][:, 8].any()
+    finally:
+        run.sys.close()
+
+
+@pytest.mark.parametrize("case,kw,nsteps", [("edl1", dict(L_n=1e-6, cation="Cs", voltage_multiplier=-5.0), 5),
+                                             ("edl50", dict(cation="Cs", voltage_multiplier=-10.0), 3)])
+def test_edl_time_loop_matches_golden(case, kw, nsteps, gpu_lib):
+    from gmpnp_amd.edl1d import EDLRun
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    run = EDLRun(num_steps=nsteps, **kw)
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        for k in range(nsteps):
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
+    finally:
+        run.sys.close()
+
+
+def test_full_size_properties(pore50, gpu_lib):
+    """Size-independent properties on the north-star mesh: Newton reduces the residual monotonically once the bc rows
+    are absorbed, the update direction satisfies J dx = b, two handles give bitwise-identical results, and the driver
+    state round-trips through the file-order permutation."""
+    pp, mesh, prob, _ = pore50
+    nv = mesh.num_vertices
+    u, un = random_state(nv, 8, seed=7)
+    with gpu_lib.DeviceSolver(prob) as a, gpu_lib.DeviceSolver(prob) as b:
+        for d in (a, b):
+            d.set_state(u, un)
+        assert np.array_equal(a.get_state(), u) and np.array_equal(a.get_state(previous=True), un)
+        Fa, na = a.assemble(True)
+        Fb, nb = b.assemble(True)
+        assert np.array_equal(Fa, Fb) and na == nb
+        xa, sta = a.linear_solve(Fa)
+        xb, stb = b.linear_solve(Fb)
+        assert np.array_equal(xa, xb) and sta == stb  # deterministic reductions, no atomics
+        assert relerr(a.spmv(xa), Fa) < 2e-10
+        a.set_state(np.zeros(prob.ndof), np.tile(np.r_[np.ones(8), 0.0], nv))
+        st = a.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        r = np.array(st["residuals"])
+        assert st["converged"] and np.all(r[2:] < r[1:-1])
+        assert np.allclose(r[3:] / r[2:-1], 0.1, rtol=0.25)  # omega = 0.9: error x0.1 per iteration near the solution
+        assert a.n_aggregates == 15 and a.jacobian_nnz == 3931821
+
+
+def test_dirichlet_and_model_updates(pore10, gpu_lib):
+    pp, mesh, prob, bnd = pore10
+    from gmpnp_amd.problem import pore_dirichlet
+    u, un = random_state(mesh.num_vertices, 8, seed=8)
+    p2 = copy.copy(prob)
+    p2.bc_dofs, p2.bc_vals = pore_dirichlet(pp, bnd, 3.21)
+    m2 = copy.deepcopy(prob.model)
+    m2.inv_dt *= 7.0
+    m2.exit_kappa = m2.exit_kappa * 2.0
+    p3 = copy.copy(p2)
+    p3.model = m2
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.set_dirichlet(p2.bc_dofs, p2.bc_vals)
+        F, _ = dev.assemble(True)
+        Fo, Ao = O.assemble(p2, u, un)
+        assert relerr(F, Fo) < 1e-12
+        dev.set_model(m2)
+        F, _ = dev.assemble(True)
+        Fo, Ao = O.assemble(p3, u, un)
+        assert relerr(F, Fo) < 1e-12 and frob_rel(dev.jacobian_csr(), Ao) < 1e-12
+
+
+def test_invalid_arguments(pore10, gpu_lib):
+    prob = pore10[2]
+    with gpu_lib.DeviceSolver(prob) as dev:
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.set_dirichlet([prob.ndof + 5], [0.0])
+        assert ei.value.code == gpu_lib.ERR_INVALID
+        with pytest.raises(gpu_lib.GmpnpError):
+            dev.jacobian_csr()  # nothing assembled yet
+        bad = copy.deepcopy(prob.model)
+        bad.species = bad.species[:-1]
+        with pytest.raises((gpu_lib.GmpnpError, ValueError, IndexError)):
+            dev.set_model(bad)
+    p = copy.copy(prob)
+    p.cells = prob.cells.copy()
+    p.cells[0, 0] = prob.coords.shape[0] + 3
+    with pytest.raises(gpu_lib.GmpnpError) as ei:
+        gpu_lib.DeviceSolver(p, perm=np.arange(prob.coords.shape[0], dtype=np.int32))
+    assert ei.value.code == gpu_lib.ERR_INVALID
+
+
+def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
+    """Output layout of the 3D and 1D drivers: file names, npz keys, shapes, metadata keys."""
+    import json
+    monkeypatch.setenv("GMPNP_OUT", str(tmp_path))
+    from gmpnp_amd import edl1d, pore3d
+    out = pore3d.main(["--L=10e-9", "--R=5e-9", "--concentration_elec=0.5", "--num_steps=2"])
+    files = set(os.listdir(out))
+    assert {"arrays_unscaled.npz", "arrays_scaled.npz", "metadata.json", "solution_K.pvd", "solution_p.pvd",
+            "solution_CO2.pvd"} <= files
+    a = np.load(os.path.join(out, "arrays_unscaled.npz"))
+    nv = 1767
+    assert a["H"].shape == (3, nv) and a["p"].shape == (3, nv) and a["coor"].shape == (nv, 3)
+    assert a["field_values"].shape == (3 * nv,) and a["cat_grad"].shape == (3 * nv,) and a["tau"].shape == (2,)
+    s = np.load(os.path.join(out, "arrays_scaled.npz"))
+    assert {"coor_scaled", "psi", "t_H", "c_cat", "eps_rel", "charge_density", "CO_grad"} <= set(s.files)
+    meta = json.load(open(os.path.join(out, "metadata.json")))
+    assert {"concentration_elec", "cation", "voltage_multiplier", "H2_FE", "L", "R", "time_step", "total_sim_time",
+            "porosity", "tortuosity", "constrictivity", "y_CO2", "press_gas", "pore_geom_multiplier",
+            "electrolyte_flow_geom_multiplier", "end_time", "eq_conc_CO", "eq_conc_H2", "current_planar",
+            "CO2_min"} <= set(meta)
+    assert "v_-1.0_L_10_R_5_P_g_1.0_D_eff_1.0_Re_1.0_rough_150.0" in out
+    out1 = edl1d.main(["--L_n=1e-6", "--num_steps=3"])
+    a1 = np.load(os.path.join(out1, "arrays_unscaled.npz"))
+    assert a1["cat"].shape == (4, 1091) and a1["field_values"].shape == (1091,) and a1["coor"].shape == (1091, 1)
+    m1 = json.load(open(os.path.join(out1, "metadata.json")))
+    assert {"eps_rel_OHP", "field_OHP", "pH_OHP", "CO2_OHP_frac", "mesh_number", "mesh_structure"} <= set(m1)
+    assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")

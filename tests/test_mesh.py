@@ -1,0 +1,94 @@
+"""Mesh ingestion and DOLFIN marking semantics (reference 3D/mesh_tests.py:76-85)."""
+import os
+
+import numpy as np
+import pytest
+
+from gmpnp_amd.mesh import (Mesh, mark_pore_boundaries, pore_wall_tolerance, read_dolfin_xml, resolve_mesh_path,
+                            write_dolfin_xml)
+from gmpnp_amd.params import utilities_dir
+
+UTIL = utilities_dir()
+
+# (file, vertices, cells, aspect R/L, tol, exterior S1/S3/S2 facets, interior wall facets, p-Dirichlet vertices)
+TABLE = [
+    ("L_50_R_1.xml", 1367, 4462, 1 / 50, 1e-3, (0, 0, 2056), 7895, 1367),
+    ("L_50_R_2.xml", 1866, 7297, 2 / 50, 1e-3, (95, 95, 2066), 5072, 1476),
+    ("L_50_R_2.5.xml", 3530, 16352, 2.5 / 50, 1e-3, (112, 112, 2656), 3771, 1762),
+    ("L_50_R_4.xml", 3238, 15057, 4 / 50, 1e-3, (112, 112, 2432), 0, 1330),
+    ("L_50_R_5.xml", 3679, 17297, 5 / 50, 1e-3, (112, 112, 2688), 0, 1458),
+    ("L_50_R_7.5.xml", 4762, 21895, 7.5 / 50, 1e-3, (240, 240, 3648), 0, 2066),
+    ("L_50_R_10.xml", 5411, 24984, 10 / 50, 1e-3, (400, 400, 3840), 0, 2322),
+    ("L_80_R_5.xml", 3216, 14920, 5 / 80, 1e-3, (112, 112, 2400), 57, 1320),
+    ("L_25_R_5.xml", 6223, 29902, 5 / 25, 1e-3, (400, 400, 3840), 0, 2322),
+    ("L_10_R_5.xml", 1767, 7696, 5 / 10, 5e-3, (300, 308, 1152), 0, 882),
+]
+
+
+@pytest.mark.parametrize("name,nv,nc,aspect,tol,ext,interior_wall,npdir", TABLE)
+def test_marking_matches_dolfin_semantics(name, nv, nc, aspect, tol, ext, interior_wall, npdir):
+    mesh = read_dolfin_xml(resolve_mesh_path(UTIL, name))
+    assert (mesh.num_vertices, mesh.num_cells) == (nv, nc)
+    b = mark_pore_boundaries(mesh, aspect, tol)
+    assert (b.counts[1][0], b.counts[3][0], b.counts[2][0]) == ext
+    assert b.counts[2][1] == interior_wall
+    pdir = np.unique(np.concatenate([b.dirichlet_vertices[k] for k in (1, 2, 3)]))
+    assert len(pdir) == npdir
+
+
+@pytest.mark.parametrize("name,aspect", [("L_50_R_5.xml", 0.1), ("L_50_R_4.xml", 0.08), ("L_50_R_10.xml", 0.2),
+                                          ("L_25_R_5.xml", 0.2)])
+def test_wall_area_check(name, aspect):
+    """The reference's manual check: assemble(1*ds(2)) next to 2*pi*R/L (3D/mesh_tests.py:80-85)."""
+    mesh = read_dolfin_xml(resolve_mesh_path(UTIL, name))
+    b = mark_pore_boundaries(mesh, aspect, 1e-3)
+    area = mesh.facet_areas(b.ds_facets[2]).sum()
+    assert abs(area - 2 * np.pi * aspect) / (2 * np.pi * aspect) < 5e-3  # inscribed polygon: slightly smaller
+    assert area < 2 * np.pi * aspect
+    vol = mesh.cell_volumes().sum()
+    assert abs(vol - np.pi * aspect ** 2) / (np.pi * aspect ** 2) < 1.5e-2
+
+
+def test_wall_tolerance_branch():
+    assert pore_wall_tolerance(10.0e-9, 5.0e-9) == 5e-3
+    assert pore_wall_tolerance(10.0e-9, 50.0e-9) == 5e-3
+    assert pore_wall_tolerance(50.0e-9, 5.0e-9) == 1e-3
+
+
+@pytest.mark.parametrize("name,nv", [("1D_variable_1um_mesh_1090.xml.gz", 1091), ("1D_variable_5um_mesh_1490.xml.gz", 1491),
+                                      ("1D_variable_10um_mesh_1990.xml.gz", 1991), ("1D_variable_50um_mesh_5990.xml.gz", 5991),
+                                      ("1D_variable_200um_mesh_4998.xml.gz", 4999)])
+def test_interval_meshes(name, nv):
+    mesh = read_dolfin_xml(resolve_mesh_path(UTIL, name))
+    assert mesh.dim == 1 and mesh.num_vertices == nv and mesh.num_cells == nv - 1
+    x = mesh.coords[:, 0]
+    assert x.min() == 0.0 and abs(x.max() - 1.0) < 1e-12
+    assert np.all(np.diff(x) > 0)
+    assert abs(mesh.cell_volumes().sum() - 1.0) < 1e-12
+    _, ext, _ = mesh.facets()
+    assert list(np.nonzero(ext)[0]) == [0, nv - 1]
+
+
+def test_duplicate_mesh_files_are_identical():
+    a = read_dolfin_xml(resolve_mesh_path(UTIL, "L_50_R_2.5.xml"))
+    b = read_dolfin_xml(resolve_mesh_path(UTIL, "L_100_R_5.xml"))
+    assert np.array_equal(a.coords, b.coords) and np.array_equal(a.cells, b.cells)
+
+
+def test_roundtrip_and_missing_file(tmp_path):
+    mesh = read_dolfin_xml(resolve_mesh_path(UTIL, "L_10_R_5.xml"))
+    for fn in ("m.xml", "m.xml.gz"):
+        p = str(tmp_path / fn)
+        write_dolfin_xml(mesh, p)
+        back = read_dolfin_xml(p)
+        assert np.array_equal(back.coords, mesh.coords) and np.array_equal(back.cells, mesh.cells)
+    with pytest.raises(RuntimeError):
+        read_dolfin_xml(str(tmp_path / "L_50_R_7.xml"))  # the truncated name does not exist
+    assert resolve_mesh_path(UTIL, "L_50_R_5.xml").endswith("L_50_R_5.xml.gz")
+
+
+def test_positive_orientation_not_required():
+    m = Mesh(dim=3, coords=np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]]), cells=np.array([[0, 2, 1, 3]], dtype=np.int32))
+    assert abs(m.cell_volumes()[0] - 1 / 6) < 1e-15
+    fv, ext, _ = m.facets()
+    assert len(fv) == 4 and ext.all()

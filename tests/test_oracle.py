@@ -1,0 +1,168 @@
+"""Pins of the CPU oracle (oracle/gmpnp_oracle.py): its Jacobian is the derivative of its residual, its closed-form
+element integrals agree with brute-force quadrature, DOLFIN's BC / Newton semantics, and the committed golden
+vectors (tests/golden, tools/make_golden.py)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gmpnp_oracle as O
+from conftest import GOLDEN, random_state
+from gmpnp_amd.model import Quadrature, default_quadrature
+from gmpnp_amd.problem import Problem, merge_dirichlet
+
+
+def _same_rule(dim):
+    q = default_quadrature(dim)
+    return Quadrature(q.lam_j, q.w_j, q.lam_j, q.w_j)
+
+
+@pytest.mark.parametrize("which", ["pore", "edl", "edl_pnp"])
+def test_jacobian_is_derivative_of_residual(which, pore10, edl1):
+    """Central finite differences of the element residual vs the analytic element Jacobian, with the SAME rule for
+    F and J (the reference's J rule differs from its F rule, so only then is J exactly dF/du)."""
+    rng = np.random.default_rng(1)
+    if which == "pore":
+        model, dim, ns = pore10[0].model, 3, 8
+        X = rng.uniform(0, 0.05, (4, 4, 3))
+    else:
+        model, dim, ns = copy.deepcopy(edl1[0].model), 1, 6
+        model.steric = which == "edl"
+        X = np.sort(rng.uniform(0, 1e-2, (4, 2, 1)), axis=1)
+    nn, nf = dim + 1, ns + 1
+    U = np.concatenate([rng.uniform(.5, 1.5, (4, nn, ns)), rng.uniform(-1, 0, (4, nn, 1))], 2)
+    Un = np.concatenate([rng.uniform(.5, 1.5, (4, nn, ns)), rng.uniform(-1, 0, (4, nn, 1))], 2)
+    q = _same_rule(dim)
+    Fe, Je = O.element_residual_jacobian(model, q, X, U, Un)
+    h = 1e-6
+    for b in range(nn):
+        for j in range(nf):
+            Up, Um = U.copy(), U.copy()
+            Up[:, b, j] += h
+            Um[:, b, j] -= h
+            fd = (O.element_residual_jacobian(model, q, X, Up, Un, False)[0]
+                  - O.element_residual_jacobian(model, q, X, Um, Un, False)[0]) / (2 * h)
+            ref = Je[:, :, :, b, j]
+            assert np.abs(fd - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max()), (which, b, j)
+
+
+def test_closed_form_integrals_match_brute_force(pore10):
+    """Polynomial terms are integrated in closed form; compare the whole residual with a degree-4 evaluation of the
+    polynomial integrands by the 14-point rule (exact for them), steric term switched off."""
+    rng = np.random.default_rng(2)
+    model = copy.deepcopy(pore10[0].model)
+    model.steric = False
+    X = rng.uniform(0, 0.05, (3, 4, 3))
+    U = np.concatenate([rng.uniform(.5, 1.5, (3, 4, 8)), rng.uniform(-1, 0, (3, 4, 1))], 2)
+    Un = np.concatenate([rng.uniform(.5, 1.5, (3, 4, 8)), rng.uniform(-1, 0, (3, 4, 1))], 2)
+    Fe, _ = O.element_residual_jacobian(model, default_quadrature(3), X, U, Un, False)
+    vol, g = O._geometry(X)
+    q = default_quadrature(3)
+    ref = np.zeros_like(Fe)
+    for lam, w in zip(q.lam_j, q.w_j):
+        u = np.einsum("b,ebf->ef", lam, U)
+        un = np.einsum("b,ebf->ef", lam, Un)
+        gu = np.einsum("ebf,ebd->efd", U, g)
+        for a in range(4):
+            phi, gphi = lam[a], g[:, a, :]
+            for i in range(8):
+                minusR = model.rc0[i] + u[:, :8] @ model.rc1[i] + sum(
+                    model.rc2[i, t] * u[:, bj] * u[:, bk] for t, (bj, bk) in enumerate(model.bil))
+                val = (u[:, i] - un[:, i]) * model.inv_dt * phi + np.einsum("ed,ed->e", gu[:, i], gphi) \
+                    + model.z[i] * u[:, i] * np.einsum("ed,ed->e", gu[:, 8], gphi) + minusR * phi
+                ref[:, a, i] += w * vol * val
+            eps = model.eps0 + u[:, :8] @ model.epsc
+            rho = u[:, :8] @ (model.z * model.bulk)
+            ref[:, a, 8] += w * vol * (-eps * np.einsum("ed,ed->e", gu[:, 8], gphi) + model.q * rho * phi)
+    assert np.abs(Fe - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_steric_rules_differ_only_slightly(pore10):
+    """F uses the degree-3 rule and J the degree-4 rule for the rational term; on smooth states they agree closely."""
+    pp, mesh, prob, _ = pore10
+    u, un = random_state(mesh.num_vertices, 8)
+    F1, _ = O.assemble(prob, u, un, want_jacobian=False, apply_bc=False)
+    p2 = copy.copy(prob)
+    p2.quad = _same_rule(3)
+    F2, _ = O.assemble(p2, u, un, want_jacobian=False, apply_bc=False)
+    assert 0 < np.linalg.norm(F1 - F2) / np.linalg.norm(F1) < 1e-4
+
+
+def test_assembly_bc_semantics(pore10):
+    pp, mesh, prob, bnd = pore10
+    u, un = random_state(mesh.num_vertices, 8)
+    F, A = O.assemble(prob, u, un)
+    F0, A0 = O.assemble(prob, u, un, apply_bc=False)
+    d = prob.bc_dofs
+    assert np.allclose(F[d], u[d] - prob.bc_vals)  # b = x - g
+    rows = A[d]
+    assert np.allclose(rows.diagonal(k=0) if False else A.diagonal()[d], 1.0)
+    assert abs(rows).sum() == pytest.approx(len(d))  # identity rows, nothing else
+    free = np.setdiff1d(np.arange(prob.ndof), d)
+    assert np.array_equal(F[free], F0[free]) and abs(A[free] - A0[free]).max() == 0.0  # columns are kept
+    assert A.nnz == A0.nnz  # pattern kept
+    # later DirichletBC wins on shared dofs: rim vertices carry p = V (wall, bc3) not 0 (bc1/bc2)
+    rim = np.intersect1d(bnd.dirichlet_vertices[1], bnd.dirichlet_vertices[2])
+    assert len(rim) > 0
+    vals = dict(zip(prob.bc_dofs, prob.bc_vals))
+    assert all(vals[v * 9 + 8] == pp.voltage_scaled for v in rim)
+
+
+def test_merge_dirichlet_order():
+    dofs, vals = merge_dirichlet([([0, 1], 2, 5.0), ([1, 2], 2, 7.0), ([1], 0, 1.0)], 3)
+    assert dict(zip(dofs, vals)) == {2: 5.0, 5: 7.0, 8: 7.0, 3: 1.0}
+
+
+def test_newton_stopping_rule():
+    """DOLFIN's residual criterion: tested before the first iteration; 0 iterations when already converged;
+    omega < 1 approaches Dirichlet values geometrically."""
+    from gmpnp_amd.model import Model
+    ns = 6
+    m = Model(dim=1, species=list("abcdef"), z=np.zeros(ns), bulk=np.ones(ns), a=np.zeros(ns), inv_dt=1.0, q=0.0,
+              eps0=1.0, epsc=np.zeros(ns), rc0=np.zeros(ns), rc1=np.zeros((ns, ns)), bil=[], rc2=np.zeros((ns, 0)),
+              steric=False)
+    x = np.linspace(0, 1, 6)[:, None]
+    cells = np.stack([np.arange(5), np.arange(1, 6)], 1).astype(np.int32)
+    dofs, vals = merge_dirichlet([([0], f, 2.0) for f in range(7)], 7)
+    prob = Problem(coords=x, cells=cells, model=m, bc_dofs=dofs, bc_vals=vals)
+    un = np.ones(prob.ndof)
+    u, st = O.newton_solve(prob, np.zeros(prob.ndof), un, relaxation_parameter=1.0)
+    assert st.iterations == 1 and st.converged and st.residuals[1] < 1e-10  # linear problem: one full step
+    u2, st2 = O.newton_solve(prob, u, un)
+    assert st2.iterations == 0 and st2.converged and np.array_equal(u2, u)
+    u3, st3 = O.newton_solve(prob, np.zeros(prob.ndof), un, relaxation_parameter=0.9, relative_tolerance=1e-4,
+                             absolute_tolerance=1e-4)
+    r = np.array(st3.residuals)
+    assert np.allclose(r[1:] / r[:-1], 0.1, rtol=1e-6)  # error x0.1 per damped iteration
+    assert st3.iterations == 5 if r[0] * 1e-4 > 1e-4 else st3.iterations >= 4
+    with pytest.raises(RuntimeError):
+        O.newton_solve(prob, np.zeros(prob.ndof), un, relaxation_parameter=0.5, maximum_iterations=3)
+
+
+def test_golden_elements(pore10, edl1):
+    g = np.load(os.path.join(GOLDEN, "elements.npz"))
+    from gmpnp_amd.params import edl_parameters, pore_parameters
+    pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
+    Fe, Je = O.element_residual_jacobian(pp.model, default_quadrature(3), g["X"], g["U"], g["Un"])
+    assert np.allclose(Fe, g["Fe"], rtol=1e-12, atol=0) and np.allclose(Je, g["Je"], rtol=1e-12, atol=1e-300)
+    ep = edl_parameters(L_n=1e-6, cation="Cs", voltage_multiplier=-10.0)
+    Fe1, Je1 = O.element_residual_jacobian(ep.model, default_quadrature(1), g["X1"], g["U1"], g["Un1"])
+    assert np.allclose(Fe1, g["Fe1"], rtol=1e-12, atol=0) and np.allclose(Je1, g["Je1"], rtol=1e-12, atol=1e-300)
+
+
+def test_golden_edl1_first_steps(edl1):
+    """Re-run the first two dry-run steps of the 1 um / Cs / V=-5 case (block-tridiagonal LU: fast) against the fixture."""
+    ep, mesh, prob = edl1
+    g = np.load(os.path.join(GOLDEN, "edl1_steps.npz"))
+    out = O.edl_time_loop(ep, copy.copy(prob), 2)
+    assert out["newton_its"] == list(g["newton_its"][:2])
+    assert np.abs(out["states"] - g["states"][:2]).max() <= 1e-9 * np.abs(g["states"][:2]).max()
+
+
+def test_project_gradient_of_linear_field(pore10):
+    _, mesh, _, _ = pore10
+    f = 2.0 * mesh.coords[:, 0] - 3.0 * mesh.coords[:, 2]
+    gproj = O.project_gradient(mesh.coords, mesh.cells, f, sign=-1.0)
+    assert np.allclose(gproj, np.array([-2.0, 0.0, 3.0])[None, :], atol=1e-9)
