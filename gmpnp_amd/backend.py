@@ -131,7 +131,8 @@ def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -
     nv = coords.shape[0]
     X = coords - coords.mean(axis=0)
     if coords.shape[1] == 1:
-        key = X[:, 0]
+        # interval meshes: plain path order (the block-tridiagonal direct solver needs it)
+        return np.argsort(X[:, 0], kind="stable").astype(np.int32)
     else:
         _, vecs = np.linalg.eigh(X.T @ X)
         axis = vecs[:, -1]
@@ -165,7 +166,8 @@ def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptio
     lin = ns.get("linear_solver", "default")
     ks = dict(ns.get("krylov_solver", {}))
     if lin in ("default", "lu", "mumps", "umfpack", "superlu", "superlu_dist", "petsc"):
-        o.linear_solver = LINEAR_TWOLEVEL
+        # exact-equivalent modes: 1D -> block-tridiagonal direct solve, 3D -> two-level BiCGStab at 1e-10
+        o.linear_solver = LINEAR_BLOCK_TRIDIAGONAL if dim == 1 else LINEAR_TWOLEVEL
         o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-10))
     elif lin == "bicgstab":
         o.linear_solver = LINEAR_JACOBI if ns.get("preconditioner", "default") == "jacobi" else LINEAR_TWOLEVEL

@@ -85,6 +85,8 @@ struct gmpnp_solver {
   // SpMV event sampling (eager mode)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
   int64_t spmv_launched = 0, spmv_sampled = 0; double spmv_us_sum = 0.0;
+  // block-tridiagonal direct solver (1D): cyclic-reduction pyramid
+  std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
   hipEvent_t ev_phase[6] = {};
   hipEvent_t ev_poll[2] = {};
 
@@ -365,6 +367,68 @@ int apply_minv(gmpnp_solver* s, int mode, double* dst, double scale_dst, double 
   return GMPNP_OK;
 }
 
+// ---- 1D direct solver ---------------------------------------------------------------------------
+int build_tridiagonal(gmpnp_solver* s) {
+  const Topology& t = s->t; const int nv = t.nv, nf = s->nf;
+  s->tri_ok = false;
+  if (s->dim != 1) return GMPNP_OK;
+  std::vector<int32_t> kp((size_t)nv * 3, -1);
+  for (int I = 0; I < nv; ++I)
+    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) {
+      const int J = t.cols[k];
+      if (J == I - 1) kp[(size_t)I * 3] = t.sellk[k];
+      else if (J == I) kp[(size_t)I * 3 + 1] = t.sellk[k];
+      else if (J == I + 1) kp[(size_t)I * 3 + 2] = t.sellk[k];
+      else return GMPNP_OK;  // internal order is not the path order: direct solver unavailable
+    }
+  std::vector<int> ns; for (int n = nv;; n = (n + 1) / 2) { ns.push_back(n); if (n == 1) break; }
+  size_t total = 0;
+  for (int n : ns) total += (size_t)n * (5 * nf * nf + 3 * nf);
+  HIP_TRY(s->tri_store.alloc(total));
+  HIP_TRY(s->tri_kpos.upload(kp));
+  double* p = s->tri_store.p;
+  s->tri.clear();
+  for (int n : ns) {
+    TriLevel l{}; l.n = n;
+    auto take = [&](size_t cnt) { double* q = p; p += cnt; return q; };
+    l.L = take((size_t)nf * nf * n); l.D = take((size_t)nf * nf * n); l.U = take((size_t)nf * nf * n); l.b = take((size_t)nf * n);
+    l.Li = take((size_t)nf * nf * n); l.Ui = take((size_t)nf * nf * n); l.bi = take((size_t)nf * n); l.x = take((size_t)nf * n);
+    s->tri.push_back(l);
+  }
+  const int lds = nf * (3 * nf + 1) * 64 * (int)sizeof(double);
+  HIP_TRY(hipFuncSetAttribute((const void*)k_bcr_forward<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_bcr_top<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  s->tri_ok = true;
+  return GMPNP_OK;
+}
+
+// Solve J x = rhs (device pointer, internal order) by block cyclic reduction; x stays in tri[0].x (SoA).
+template <int NF>
+int tri_solve(gmpnp_solver* s, const double* rhs) {
+  if (!s->tri_ok) return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh in path order");
+  const size_t lds = (size_t)NF * (3 * NF + 1) * 64 * sizeof(double);
+  hipLaunchKernelGGL((k_tri_extract<NF>), dim3(grid_for(s->t.nv * NF * NF, kVecBlock)), dim3(kVecBlock), 0, s->stream,
+                     s->c, s->tri[0], s->tri_kpos.p, rhs);
+  const int nl = (int)s->tri.size();
+  for (int l = 0; l + 1 < nl; ++l)
+    hipLaunchKernelGGL((k_bcr_forward<NF>), dim3(grid_for(s->tri[l + 1].n, 64)), dim3(64), lds, s->stream, s->tri[l],
+                       s->tri[l + 1], s->status.p);
+  hipLaunchKernelGGL((k_bcr_top<NF>), dim3(1), dim3(64), lds, s->stream, s->tri[nl - 1], s->status.p);
+  for (int l = nl - 2; l >= 0; --l)
+    hipLaunchKernelGGL((k_bcr_backward<NF>), dim3(grid_for(s->tri[l].n, kVecBlock)), dim3(kVecBlock), 0, s->stream,
+                       s->tri[l], s->tri[l + 1]);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+template <int NF>
+int tri_apply(gmpnp_solver* s, double* dst, double scale_dst, double scale_x) {
+  hipLaunchKernelGGL((k_tri_apply<NF>), dim3(grid_for(s->ndof, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->tri[0], dst,
+                     scale_dst, scale_x, s->ndof);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
 std::string status_message(int flags) {
   std::string m;
   if (flags & 1) m += "1 - sum_j a_j u_j <= 0 at a quadrature point; ";
@@ -397,22 +461,32 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc;
     s->jacobian_valid = true;
     HIP_TRY(hipEventRecord(s->ev_phase[1], s->stream));
-    rc = setup_preconditioner<DIM, NF>(s, o.linear_solver); if (rc) return rc;
-    // rhs = b (current residual vector F)
-    HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
-    gmpnp_linear_stats_t ls{};
-    rc = krylov<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
-                    o.krylov_maximum_iterations, &ls);
-    if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
-    st.krylov_iterations += ls.iterations;
-    if (rc) {
-      HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (*s->h_status) g_err += " [" + status_message(*s->h_status) + "]";
-      return rc;
+    if (o.linear_solver == GMPNP_LINEAR_BLOCK_TRIDIAGONAL) {
+      HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+      if constexpr (DIM == 1) {
+        rc = tri_solve<NF>(s, s->F.p); if (rc) return rc;
+        rc = tri_apply<NF>(s, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
+      } else {
+        return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh");
+      }
+    } else {
+      rc = setup_preconditioner<DIM, NF>(s, o.linear_solver); if (rc) return rc;
+      // rhs = b (current residual vector F)
+      HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+      gmpnp_linear_stats_t ls{};
+      rc = krylov<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
+                      o.krylov_maximum_iterations, &ls);
+      if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
+      st.krylov_iterations += ls.iterations;
+      if (rc) {
+        HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (*s->h_status) g_err += " [" + status_message(*s->h_status) + "]";
+        return rc;
+      }
+      // x <- x - omega dx
+      rc = apply_minv<NF>(s, o.linear_solver, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
     }
-    // x <- x - omega dx
-    rc = apply_minv<NF>(s, o.linear_solver, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
     st.iterations++;
     ta = now_ms();
@@ -569,6 +643,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.pc_part = s->pc_part.p; c.yc = s->yc.p; c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
+  rc = build_tridiagonal(s.get()); if (rc) return rc;
   // the coarse inverse keeps its whole matrix in LDS: opt in to > 64 KiB of dynamic LDS
   if (nf == 9) HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds_bytes(s->ncoarse, 9)));
   else HIP_TRY(hipFuncSetAttribute((const void*)k_coarse_invert<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds_bytes(s->ncoarse, 7)));
@@ -638,8 +713,9 @@ int gmpnp_assign_previous(gmpnp_solver* s) {
 int gmpnp_newton_solve(gmpnp_solver* s, const gmpnp_newton_options_t* o, gmpnp_newton_stats_t* stats) {
   if (!s || !o) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (o->maximum_iterations < 0 || o->krylov_maximum_iterations < 1) return fail(GMPNP_ERR_INVALID, "bad iteration limits");
-  if (o->linear_solver != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && o->linear_solver != GMPNP_LINEAR_BICGSTAB_JACOBI)
-    return fail(GMPNP_ERR_INVALID, "linear_solver not available in this build");
+  if (o->linear_solver < 0 || o->linear_solver > GMPNP_LINEAR_BLOCK_TRIDIAGONAL) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
+  if (o->linear_solver == GMPNP_LINEAR_BLOCK_TRIDIAGONAL && !s->tri_ok)
+    return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh in path order");
   gmpnp_newton_stats_t local{};
   gmpnp_newton_stats_t& st = stats ? *stats : local;
   st = gmpnp_newton_stats_t{};
@@ -717,8 +793,7 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
                        int32_t maxit, gmpnp_linear_stats_t* stats) {
   if (!s || !b || !x) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
-  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
-    return fail(GMPNP_ERR_INVALID, "linear_solver not available in this build");
+  if (mode < 0 || mode > GMPNP_LINEAR_BLOCK_TRIDIAGONAL) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
   if (maxit < 1) return fail(GMPNP_ERR_INVALID, "max_iterations < 1");
   HIP_TRY(hipSetDevice(s->opts.device_id));
   HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
@@ -726,6 +801,16 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   double bn = 0.0;
   for (int64_t i = 0; i < s->ndof; ++i) bn += b[i] * b[i];
   bn = std::sqrt(bn);
+  if (mode == GMPNP_LINEAR_BLOCK_TRIDIAGONAL) {
+    if (s->dim != 1) return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh");
+    rc = tri_solve<7>(s, s->kr.p); if (rc) return rc;
+    rc = tri_apply<7>(s, s->tmpx.p, 0.0, 1.0); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
+    if (stats) { stats->iterations = 1; stats->converged = 1; stats->residual_norm = 0.0; stats->rhs_norm = bn; }
+    return download_vec(s, s->tmpx.p, x);
+  }
   GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
   if (rc) return rc;
   gmpnp_linear_stats_t ls{};

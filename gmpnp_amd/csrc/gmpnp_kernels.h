@@ -819,4 +819,162 @@ __global__ void k_fill(double* __restrict__ a, double v, int n) {
   if (i < n) a[i] = v;
 }
 
+
+// =================================================================================================
+// Direct solver for 1D meshes: block cyclic reduction of the block-tridiagonal Jacobian (NF x NF blocks).
+// Replaces the reference's default sparse LU of the 1D script (1D/MPNP_CO2ER_EDL.py:357-364, UMFPACK) where a
+// Jacobi-type Krylov method is hopeless (q ~ 1e9, 0.1 nm cells next to 10 nm cells).
+//
+// Level l holds n_l rows in SoA form ([entry][row]); level l+1 = the even rows of level l after eliminating
+// the odd ones.  One lane per even row does both neighbour eliminations (Gauss-Jordan with partial pivoting
+// inside the NF x NF block, scratch in LDS) and keeps D_j^{-1}[L_j U_j b_j] of its right odd neighbour for the
+// back substitution.  ~log2(n) launches down and up; no atomics, deterministic.
+// =================================================================================================
+struct TriLevel {
+  int n;
+  double *L, *D, *U, *b;     // [NF*NF][n] x3, [NF][n]
+  double *Li, *Ui, *bi;      // D^{-1}L, D^{-1}U, D^{-1}b of the odd rows
+  double* x;                 // [NF][n]
+};
+
+// Solve Dm X = [Lm | Um | bm] for row j of level lv; result left in W[(r*(3*NF+1) + NF + c)*64 + t], c in [0, 2NF].
+template <int NF>
+__device__ inline bool tri_inv_apply(const TriLevel& lv, int j, double* W, int t) {
+  constexpr int NC = 3 * NF + 1;
+  for (int r = 0; r < NF; ++r) {
+    for (int cI = 0; cI < NF; ++cI) {
+      W[(r * NC + cI) * 64 + t] = lv.D[(size_t)(r * NF + cI) * lv.n + j];
+      W[(r * NC + NF + cI) * 64 + t] = lv.L[(size_t)(r * NF + cI) * lv.n + j];
+      W[(r * NC + 2 * NF + cI) * 64 + t] = lv.U[(size_t)(r * NF + cI) * lv.n + j];
+    }
+    W[(r * NC + 3 * NF) * 64 + t] = lv.b[(size_t)r * lv.n + j];
+  }
+  for (int k = 0; k < NF; ++k) {
+    int p = k; double best = fabs(W[(k * NC + k) * 64 + t]);
+    for (int r = k + 1; r < NF; ++r) { const double v = fabs(W[(r * NC + k) * 64 + t]); if (v > best) { best = v; p = r; } }
+    if (!(best > 0.0)) return false;
+    if (p != k)
+      for (int cI = k; cI < NC; ++cI) { const double tmp = W[(k * NC + cI) * 64 + t]; W[(k * NC + cI) * 64 + t] = W[(p * NC + cI) * 64 + t]; W[(p * NC + cI) * 64 + t] = tmp; }
+    const double ip = 1.0 / W[(k * NC + k) * 64 + t];
+    for (int cI = k; cI < NC; ++cI) W[(k * NC + cI) * 64 + t] *= ip;
+    for (int r = 0; r < NF; ++r) {
+      if (r == k) continue;
+      const double f = W[(r * NC + k) * 64 + t];
+      if (f == 0.0) continue;
+      for (int cI = k; cI < NC; ++cI) W[(r * NC + cI) * 64 + t] -= f * W[(k * NC + cI) * 64 + t];
+    }
+  }
+  return true;
+}
+
+template <int NF>
+__global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, int32_t* status) {
+  constexpr int NC = 3 * NF + 1;
+  extern __shared__ double W[];  // [NF*NC][64]
+  const int t = threadIdx.x, ih = blockIdx.x * 64 + t;  // row of the upper level
+  if (ih >= hi.n) return;
+  const int i = 2 * ih;
+  bool ok = true;
+  // start from row i itself
+  for (int e = 0; e < NF * NF; ++e) {
+    hi.D[(size_t)e * hi.n + ih] = lo.D[(size_t)e * lo.n + i];
+    hi.L[(size_t)e * hi.n + ih] = 0.0;
+    hi.U[(size_t)e * hi.n + ih] = 0.0;
+  }
+  for (int r = 0; r < NF; ++r) hi.b[(size_t)r * hi.n + ih] = lo.b[(size_t)r * lo.n + i];
+  for (int side = 0; side < 2; ++side) {
+    const int j = side == 0 ? i - 1 : i + 1;
+    if (j < 0 || j >= lo.n) continue;
+    ok &= tri_inv_apply<NF>(lo, j, W, t);
+    const double* C = side == 0 ? lo.L : lo.U;  // coupling of row i to row j
+    for (int r = 0; r < NF; ++r) {
+      double cr[NF];
+#pragma unroll
+      for (int mI = 0; mI < NF; ++mI) cr[mI] = C[(size_t)(r * NF + mI) * lo.n + i];
+      for (int cI = 0; cI < NF; ++cI) {
+        double sL = 0.0, sU = 0.0;
+#pragma unroll
+        for (int mI = 0; mI < NF; ++mI) { sL += cr[mI] * W[(mI * NC + NF + cI) * 64 + t]; sU += cr[mI] * W[(mI * NC + 2 * NF + cI) * 64 + t]; }
+        if (side == 0) { hi.L[(size_t)(r * NF + cI) * hi.n + ih] = -sL; hi.D[(size_t)(r * NF + cI) * hi.n + ih] -= sU; }
+        else { hi.D[(size_t)(r * NF + cI) * hi.n + ih] -= sL; hi.U[(size_t)(r * NF + cI) * hi.n + ih] = -sU; }
+      }
+      double sb = 0.0;
+#pragma unroll
+      for (int mI = 0; mI < NF; ++mI) sb += cr[mI] * W[(mI * NC + 3 * NF) * 64 + t];
+      hi.b[(size_t)r * hi.n + ih] -= sb;
+    }
+    if (side == 1) {  // keep the right neighbour's solved couplings for the way back up
+      for (int r = 0; r < NF; ++r) {
+        for (int cI = 0; cI < NF; ++cI) {
+          lo.Li[(size_t)(r * NF + cI) * lo.n + j] = W[(r * NC + NF + cI) * 64 + t];
+          lo.Ui[(size_t)(r * NF + cI) * lo.n + j] = W[(r * NC + 2 * NF + cI) * 64 + t];
+        }
+        lo.bi[(size_t)r * lo.n + j] = W[(r * NC + 3 * NF) * 64 + t];
+      }
+    }
+  }
+  if (!ok) atomicOr(status, 2);
+}
+
+// top of the pyramid: one row, x = D^{-1} b
+template <int NF>
+__global__ __launch_bounds__(64) void k_bcr_top(TriLevel top, int32_t* status) {
+  extern __shared__ double W[];
+  constexpr int NC = 3 * NF + 1;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!tri_inv_apply<NF>(top, 0, W, 0)) { atomicOr(status, 2); return; }
+  for (int r = 0; r < NF; ++r) top.x[r] = W[(r * NC + 3 * NF) * 64];
+}
+
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_bcr_backward(TriLevel lo, TriLevel hi) {
+  const int j = blockIdx.x * kVecBlock + threadIdx.x;
+  if (j >= lo.n) return;
+  if ((j & 1) == 0) {
+#pragma unroll
+    for (int r = 0; r < NF; ++r) lo.x[(size_t)r * lo.n + j] = hi.x[(size_t)r * hi.n + (j >> 1)];
+    return;
+  }
+  double xl[NF], xr[NF];
+  const bool has_r = (j + 1 < lo.n);
+#pragma unroll
+  for (int r = 0; r < NF; ++r) {
+    xl[r] = hi.x[(size_t)r * hi.n + ((j - 1) >> 1)];
+    xr[r] = has_r ? hi.x[(size_t)r * hi.n + ((j + 1) >> 1)] : 0.0;
+  }
+  for (int r = 0; r < NF; ++r) {
+    double s = lo.bi[(size_t)r * lo.n + j];
+#pragma unroll
+    for (int cI = 0; cI < NF; ++cI)
+      s -= lo.Li[(size_t)(r * NF + cI) * lo.n + j] * xl[cI] + lo.Ui[(size_t)(r * NF + cI) * lo.n + j] * xr[cI];
+    lo.x[(size_t)r * lo.n + j] = s;
+  }
+}
+
+// SELL Jacobian + right-hand side -> level-0 SoA arrays (internal order must be the path order of the interval mesh)
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_tri_extract(const Ctx c, TriLevel l0, const int32_t* __restrict__ tri_kpos,
+                                                           const double* __restrict__ rhs) {
+  constexpr int S = kWave / NF;
+  const int idx = blockIdx.x * kVecBlock + threadIdx.x;
+  if (idx >= c.nv * NF * NF) return;
+  const int e = idx / c.nv, I = idx - e * c.nv, i = e / NF, j = e - i * NF;
+  const int s = I / S, il = I - s * S;
+  const double* base = c.vals + c.slice_off[s] + il * NF + i;
+  const int kl = tri_kpos[I * 3], kd = tri_kpos[I * 3 + 1], kr = tri_kpos[I * 3 + 2];
+  l0.L[idx] = kl >= 0 ? base[(size_t)(kl * NF + j) * kWave] : 0.0;
+  l0.D[idx] = base[(size_t)(kd * NF + j) * kWave];
+  l0.U[idx] = kr >= 0 ? base[(size_t)(kr * NF + j) * kWave] : 0.0;
+  if (e < NF) l0.b[(size_t)e * c.nv + I] = rhs[(size_t)I * NF + e];
+}
+
+// dst[I*NF+f] = scale_dst*dst + scale_x * x[f][I]
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_tri_apply(TriLevel l0, double* __restrict__ dst, double scale_dst, double scale_x, int ndof) {
+  const int r = blockIdx.x * kVecBlock + threadIdx.x;
+  if (r >= ndof) return;
+  const int I = r / NF, f = r - I * NF;
+  dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * l0.x[(size_t)f * l0.n + I];
+}
+
 }  // namespace gmpnp

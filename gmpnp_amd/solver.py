@@ -37,7 +37,7 @@ class GMPNPSystem:
 
     def solve(self, solver_parameters=None):
         """``solve(F == 0, u, bcs, solver_parameters=...)``.  RuntimeError on non-convergence, as DOLFIN."""
-        opts = backend.newton_options(solver_parameters)
+        opts = backend.newton_options(solver_parameters, dim=self.problem.coords.shape[1])
         try:
             st = self.dev.newton_solve(opts)
         except backend.GmpnpError as e:

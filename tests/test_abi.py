@@ -77,7 +77,9 @@ def test_newton_options_translation(backend):
     assert o.krylov_relative_tolerance == 1e-10
     d = backend.newton_options({"newton_solver": {"maximum_iterations": 50, "relative_tolerance": 1e-4,
                                                   "absolute_tolerance": 1e-4}})
-    assert d.relaxation_parameter == 1.0 and d.linear_solver == backend.LINEAR_TWOLEVEL  # 1D defaults (1D:357-364)
+    assert d.relaxation_parameter == 1.0 and d.linear_solver == backend.LINEAR_TWOLEVEL  # [3P] defaults (1D:357-364)
+    d1 = backend.newton_options({"newton_solver": {"maximum_iterations": 50}}, dim=1)
+    assert d1.linear_solver == backend.LINEAR_BLOCK_TRIDIAGONAL  # default LU of the 1D script -> direct solver
     j = backend.newton_options({"newton_solver": {"linear_solver": "bicgstab", "preconditioner": "jacobi",
                                                   "krylov_solver": {"relative_tolerance": 1e-8}}})
     assert j.linear_solver == backend.LINEAR_JACOBI and j.krylov_relative_tolerance == 1e-8

@@ -87,9 +87,8 @@ def test_steric_guard_reports_instead_of_nan(pore10, gpu_lib):
         assert ei.value.code == gpu_lib.ERR_NUMERIC
 
 
-@pytest.mark.parametrize("case", ["pore10", "edl1"])
-def test_spmv_and_linear_solve(case, request, gpu_lib):
-    prob = request.getfixturevalue(case)[2]
+def test_spmv_and_linear_solve_3d(pore10, gpu_lib):
+    prob = pore10[2]
     nv, ns = prob.coords.shape[0], prob.nf - 1
     u, un = random_state(nv, ns, seed=5)
     rng = np.random.default_rng(6)
@@ -104,12 +103,11 @@ def test_spmv_and_linear_solve(case, request, gpu_lib):
         y1, y2 = dev.spmv(x), dev.spmv(2.5 * x)
         assert relerr(y2, 2.5 * y1) < 1e-15
         xs, st = dev.linear_solve(Fo, gpu_lib.LINEAR_TWOLEVEL, 1e-10, 0.0, 5000)
-        assert st["converged"] and relerr(Ao @ xs, Fo) < 2e-10
-        assert relerr(xs, xo) < 1e-8 if case == "pore10" else relerr(Ao @ xs, Fo) < 2e-10
-        if case == "pore10":
-            xj, stj = dev.linear_solve(Fo, gpu_lib.LINEAR_JACOBI, 1e-10, 0.0, 20000)
-            assert stj["converged"] and relerr(xj, xo) < 1e-8
-            assert stj["iterations"] > 3 * st["iterations"]  # the coarse correction pays
+        assert st["converged"] and relerr(Ao @ xs, Fo) < 2e-10 and relerr(xs, xo) < 1e-6
+        xj, stj = dev.linear_solve(Fo, gpu_lib.LINEAR_JACOBI, 1e-10, 0.0, 20000)
+        # ||x - x*|| <= cond(J) * residual: on this random (unphysical) state only the residual is tight
+        assert stj["converged"] and relerr(Ao @ xj, Fo) < 2e-10 and relerr(xj, xo) < 1e-3
+        assert stj["iterations"] > 3 * st["iterations"]  # the coarse correction pays
         # zero right-hand side
         xz, stz = dev.linear_solve(np.zeros(prob.ndof), gpu_lib.LINEAR_TWOLEVEL, 1e-10, 0.0, 100)
         assert not xz.any() and stz["iterations"] == 0
@@ -117,6 +115,31 @@ def test_spmv_and_linear_solve(case, request, gpu_lib):
         with pytest.raises(gpu_lib.GmpnpError) as ei:
             dev.linear_solve(Fo, gpu_lib.LINEAR_JACOBI, 1e-14, 0.0, 3)
         assert ei.value.code == gpu_lib.ERR_LINEAR
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.linear_solve(Fo, gpu_lib.LINEAR_BLOCK_TRIDIAGONAL)
+        assert ei.value.code == gpu_lib.ERR_INVALID
+
+
+@pytest.mark.parametrize("case", ["edl1", "edl50"])
+def test_spmv_and_direct_solve_1d(case, request, gpu_lib):
+    """Block cyclic reduction against SciPy's sparse LU on the 1D Jacobian (q ~ 4e5 ... 1e9)."""
+    prob = request.getfixturevalue(case)[2]
+    nv = prob.coords.shape[0]
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    u, un = g["states"][1], g["states"][0]  # a physical state: second dry-run step
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(prob.ndof)
+    Fo, Ao = O.assemble(prob, u, un)
+    b = rng.standard_normal(prob.ndof)
+    lu = spla.splu(Ao.tocsc())
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.assemble(True)
+        assert relerr(dev.spmv(x), Ao @ x) < 1e-13
+        for rhs in (Fo, b):
+            xs, st = dev.linear_solve(rhs, gpu_lib.LINEAR_BLOCK_TRIDIAGONAL)
+            xo = lu.solve(rhs)
+            assert st["converged"] and relerr(xs, xo) < 1e-8
 
 
 def test_newton_first_step_matches_oracle(pore10, gpu_lib):
@@ -128,9 +151,13 @@ def test_newton_first_step_matches_oracle(pore10, gpu_lib):
         dev.set_state(u0, un)
         st = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
         u = dev.get_state()
-        # converged state: the convergence test runs before the first iteration -> 0 Newton iterations
+        # the relative test is relative to the entry residual of EACH solve, so a second solve iterates until the
+        # absolute test passes; a third one then performs 0 iterations (the test runs before the first iteration)
+        st1 = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        assert st1["residuals"][0] == pytest.approx(st["residuals"][-1], rel=1e-12) and st1["residuals"][-1] < 1e-4
+        u1 = dev.get_state()
         st0 = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
-        assert st0["iterations"] == 0 and st0["converged"] and np.array_equal(dev.get_state(), u)
+        assert st0["iterations"] == 0 and st0["converged"] and np.array_equal(dev.get_state(), u1)
     assert st["iterations"] == int(g["newton_its"][0]) == 7
     ref = g["residuals"][0][:8]
     assert np.allclose(st["residuals"], ref, rtol=1e-7)
