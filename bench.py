@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Newton iterations / second (+ achieved HBM GB/s of the dominant kernel) of the 3D pore
+case of BASELINE.json (configs[2]: MPNP_CO2ER_pore, L_50_R_5.xml, 0.5 M KHCO3, V = -1) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one time step of the reference's loop (3D/MPNP_CO2ER_pore.py:783-858): a damped Newton solve on the
+device (residual/Jacobian assembly, two-level BiCGStab, update) plus the per-step host glue (vertex values back,
+median -> Sechenov -> new Dirichlet value, u_n.assign(u)).  W warm-up steps run first and are discarded (state reset to
+t = 0), then EXACTLY K steps from t = 0 are timed between barrier + synchronize pairs; value = Newton iterations of
+all ranks / max-over-ranks time.
+
+N > 1 (this round): one independent L_50_R_5 problem per GPU (the parameter-sweep mapping of BASELINE configs[4],
+"replicas only", no data-path collective) -> weak scaling.  The mesh-partitioned single-problem solve with RCCL halo
+exchange is not wired into this bench yet (multi-GPU).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = SELL block SpMV (2 launches per BiCGStab iteration).  achieved = algorithmic bytes
+                of one SpMV (648 nb + 4 nb + 4 (nv+1) + 16 nd) / mean launch duration, sampled LIVE with
+                HIP events on the solver's own stream during the timed region (every 8th launch).
+  cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU, one thread) timed on rank 0 / N = 1 for ONE Newton
+                iteration of the same workload (about 20-30 s); kind = "port" (FEniCS itself cannot be installed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--mesh", type=str, default="L_50_R_5", help="L_<nm>_R_<nm> pore mesh (default: the north-star mesh)")
+    return p.parse_args()
+
+
+def cpu_baseline(run):
+    """One Newton iteration of time step 0 with the oracle (test infrastructure used here only as the timed CPU leg)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gmpnp_oracle as O
+    import scipy.sparse.linalg as spla
+    prob = run.problem
+    nv = run.mesh.num_vertices
+    u = np.zeros(prob.ndof)
+    un = np.tile(np.r_[np.ones(8), 0.0], nv)
+    O.assemble(prob, u, un)  # builds the scatter pattern once (one-off set-up, like DOLFIN's sparsity pattern)
+    t0 = time.perf_counter()
+    b, A = O.assemble(prob, u, un, want_jacobian=True)
+    t1 = time.perf_counter()
+    dx = spla.splu(A.tocsc()).solve(b)
+    t2 = time.perf_counter()
+    u = u - 0.9 * dx
+    O.assemble(prob, u, un, want_jacobian=False)
+    t3 = time.perf_counter()
+    return {"value": 1.0 / (t3 - t0), "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
+            "sample": "1 Newton iteration of time step 0 (same mesh/parameters): NumPy P1 assembly of J and F "
+                      "%.1f s + SciPy SuperLU factor+solve %.1f s + residual re-assembly %.1f s; FEniCS/MUMPS "
+                      "itself is not installable on this box" % (t1 - t0, t2 - t1, t3 - t2),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if a.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    from gmpnp_amd.pore3d import PoreRun
+    from gmpnp_amd.problem import pore_dirichlet
+
+    _, Lnm, _, Rnm = a.mesh.split("_")
+    run = PoreRun(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9,
+                  device_kwargs={"device_id": local, "use_graph": False, "profile_every": 8})
+    nv = run.mesh.num_vertices
+
+    def reset():
+        run.sys.set_bcs(*pore_dirichlet(run.pp, run.bnd))
+        run.sys.initialise([1.0] * 8 + [0.0])
+        run.history = run.history[:1]
+        run.newton_its, run.n, run.t = [], 0, 0.0
+        run.sys.krylov_iterations = 0
+
+    for _ in range(a.warmup):
+        run.step(verbose=False)
+    reset()
+    run.sys.dev.spmv_profile()  # clear the sampler
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run.step(verbose=False)
+    fence()
+    dt = time.perf_counter() - t0
+
+    its = float(sum(run.newton_its))
+    kry = float(run.sys.krylov_iterations)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([its, kry], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        dt, its, kry = float(t[0]), float(s[0]), float(s[1])
+
+    if rank == 0:
+        dev = run.sys.dev
+        prof = dev.spmv_profile()
+        nb, nd = dev.n_blocks, dev.ndof
+        nf = dev.nf
+        alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
+        mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(0, 200)
+        achieved = alg_bytes / (mean_us * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")
+        if os.path.exists(pmc) and a.mesh == "L_50_R_5":
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "newton_iterations_per_sec", "value": its / dt, "unit": "Newton-iterations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "reference inputs shipped in data/utilities (%s mesh, parameters_pore.yaml, bulk_soln_0.5KHCO3.yaml); "
+                    "deterministic, no RNG" % a.mesh,
+            "config": {"workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
+                                   "(Newton rtol=atol=1e-4, omega=0.9, max 50; linear solve = two-level BiCGStab to "
+                                   "1e-10 relative residual)" % (a.mesh, a.steps - 1),
+                       "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,
+                       "krylov_iterations": kry,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL node-block SpMV, fp64)", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
+                         "launches_sampled": prof["sampled"], "launches_total": prof["launched"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(run)
+        print(json.dumps(out), flush=True)
+    run.sys.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
