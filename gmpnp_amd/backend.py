@@ -77,7 +77,7 @@ def load_library(path: str = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GMPNP_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise RuntimeError("HIP backend %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % p)

@@ -8,6 +8,10 @@
 #include <cstring>
 #include <memory>
 
+#ifndef GMPNP_SPMV_WAVES
+#define GMPNP_SPMV_WAVES 8
+#endif
+
 #include "gmpnp_kernels.h"
 
 using namespace gmpnp;
@@ -69,7 +73,7 @@ struct gmpnp_solver {
   DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, Dinv, AP, AcPart, Ac, AciT;
   DevBuf<double> kr, krhat, kp, kv, ks, kt, ky, kq, pc_part, yc, part_rr, part_a, part_b, part_f, tmpx;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
-      sell_cols, sell_blk, wl_slice, wl_kpos, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
+      sell_cols, sell_blk, wl_slice, wl_kpos, vw_agg, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
   DevBuf<int64_t> rob_addr, slice_off;
   DevBuf<uint8_t> bcflag, sell_aggslot;
   DevBuf<KrylovScalars> scal;
@@ -111,6 +115,8 @@ namespace {
     else if ((s)->dim == 1 && (s)->nf == 7) { constexpr int DIM = 1, NF = 7; CALL; } \
     else return fail(GMPNP_ERR_INVALID, "unsupported (dim, n_fields)"); \
   } while (0)
+
+constexpr int kSpmvWaves = GMPNP_SPMV_WAVES;  // waves per SELL slice in k_spmv
 
 int grid_for(int n, int block) { return (n + block - 1) / block; }
 
@@ -254,7 +260,7 @@ int launch_spmv(gmpnp_solver* s, const double* x, double* out, bool sample) {
     ev = &s->ev_pool[s->ev_used++];
     HIP_TRY(hipEventRecord(ev->first, s->stream));
   }
-  hipLaunchKernelGGL((k_spmv<NF, MODE>), dim3(s->t.nslices), dim3(kVecBlock), 0, s->stream, s->c, x, out);
+  hipLaunchKernelGGL((k_spmv<NF, MODE, kSpmvWaves>), dim3(s->t.nslices), dim3(kSpmvWaves * 64), 0, s->stream, s->c, x, out);
   if (ev) HIP_TRY(hipEventRecord(ev->second, s->stream));
   s->spmv_launched++;
   return GMPNP_OK;
@@ -273,12 +279,13 @@ int drain_spmv_events(gmpnp_solver* s) {
 template <int NF>
 int enqueue_iteration(gmpnp_solver* s, int use_coarse, bool allow_sampling) {
   const int every = s->opts.profile_every;
+  const dim3 cg(grid_for(s->ncoarse, 4)), cb(kVecBlock);
   hipLaunchKernelGGL((k_vec1<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_coarse<NF>), cg, cb, 0, s->stream, s->c, use_coarse);
   int rc = launch_spmv<NF, 1>(s, s->kq.p, s->kv.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
   if (rc) return rc;
   hipLaunchKernelGGL((k_vec2<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
+  hipLaunchKernelGGL((k_coarse<NF>), cg, cb, 0, s->stream, s->c, use_coarse);
   rc = launch_spmv<NF, 2>(s, s->kq.p, s->kt.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
   return rc;
 }
@@ -615,9 +622,9 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->AciT.alloc((size_t)s->ncoarse * s->ncoarse));
-  HIP_TRY(s->vw_node0.upload(t.vw_node0)); HIP_TRY(s->vw_node1.upload(t.vw_node1)); HIP_TRY(s->agg_vw_ptr.upload(t.agg_vw_ptr));
+  HIP_TRY(s->vw_node0.upload(t.vw_node0)); HIP_TRY(s->vw_node1.upload(t.vw_node1)); HIP_TRY(s->agg_vw_ptr.upload(t.agg_vw_ptr)); HIP_TRY(s->vw_agg.upload(t.vw_agg));
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp, &s->kv, &s->ks, &s->kt, &s->ky, &s->kq, &s->tmpx}) HIP_TRY(b->alloc(ndof));
-  HIP_TRY(s->pc_part.alloc((size_t)n_vecwg * nf)); HIP_TRY(s->yc.alloc(kMaxCoarse));
+  HIP_TRY(s->pc_part.alloc((size_t)s->ncoarse * t.vw_slots)); HIP_TRY(s->yc.alloc(kMaxCoarse));
   HIP_TRY(s->part_rr.alloc(n_vecwg)); HIP_TRY(s->part_a.alloc(t.nslices)); HIP_TRY(s->part_b.alloc((size_t)4 * t.nslices));
   HIP_TRY(s->part_f.alloc(s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
@@ -638,7 +645,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.sell_cols = s->sell_cols.p; c.sell_aggslot = s->sell_aggslot.p; c.wl_slice = s->wl_slice.p; c.wl_kpos = s->wl_kpos.p;
   c.sell_blk = s->sell_blk.p; c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
   c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.AciT = s->AciT.p;
-  c.vw_node0 = s->vw_node0.p; c.vw_node1 = s->vw_node1.p; c.agg_vw_ptr = s->agg_vw_ptr.p;
+  c.vw_node0 = s->vw_node0.p; c.vw_node1 = s->vw_node1.p; c.agg_vw_ptr = s->agg_vw_ptr.p; c.vw_agg = s->vw_agg.p; c.vw_slots = t.vw_slots;
   c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp = s->kp.p; c.kv = s->kv.p; c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kq = s->kq.p;
   c.pc_part = s->pc_part.p; c.yc = s->yc.p; c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;

@@ -89,6 +89,8 @@ struct Ctx {
   const int32_t* vw_node0;      // [n_vecwg]
   const int32_t* vw_node1;
   const int32_t* agg_vw_ptr;    // [nagg+1]
+  const int32_t* vw_agg;        // [n_vecwg] aggregate of each vector workgroup
+  int32_t vw_slots;             // partial-sum slots per coarse dof (>= workgroups per aggregate)
   // Krylov vectors
   double* kr;    // r
   double* krhat;
@@ -98,7 +100,7 @@ struct Ctx {
   double* kt;
   double* ky;
   double* kq;    // Dinv * (p or s)
-  double* pc_part;  // [n_vecwg][NF]
+  double* pc_part;  // [ncoarse][vw_slots] restriction partials, slot = workgroup index inside its aggregate
   double* yc;       // [ncoarse]
   double* part_rr;  // [n_vecwg]
   double* part_a;   // [nslices]      (rhat, v)
@@ -122,7 +124,8 @@ struct Topology {
   std::vector<uint8_t> sell_aggslot;
   int nagg = 0;
   std::vector<int32_t> agg, agg_start, row_aggs;
-  std::vector<int32_t> vw_node0, vw_node1, agg_vw_ptr;
+  std::vector<int32_t> vw_node0, vw_node1, agg_vw_ptr, vw_agg;
+  int vw_slots = 0;
 };
 
 // Builds every table above; returns an error message or "" on success.

@@ -616,8 +616,9 @@ __global__ __launch_bounds__(512) void k_coarse_invert(const Ctx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Coarse solve yc = Aci pc, one wave per coarse row (4 rows per workgroup); pc = sum of the restriction
-// partials of each aggregate in a fixed order, rebuilt in LDS by every workgroup (a few KB from L2).
+// Coarse solve yc = Aci pc, one wave per coarse row (4 rows per workgroup).  pc = fixed-order sum of the
+// restriction partials pc_part[coarse dof][slot] (slots of absent workgroups stay zero).  The matrix row and
+// the partials are requested together, so the kernel is one memory round trip plus a wave reduction.
 // ---------------------------------------------------------------------------------------------
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_coarse(const Ctx c, int use_coarse) {
@@ -626,39 +627,47 @@ __global__ __launch_bounds__(kVecBlock) void k_coarse(const Ctx c, int use_coars
   const int n = c.ncoarse, t = threadIdx.x;
   const int row = blockIdx.x * 4 + (t >> 6), lane = t & 63;
   if (!use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
+  double a[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int cc = lane + 64 * k; a[k] = (row < n && cc < n) ? c.AciT[(size_t)row * n + cc] : 0.0; }
   if (t < n) {
-    const int g = t / NF, f = t - g * NF;
+    const double* pp = c.pc_part + (size_t)t * c.vw_slots;
     double s = 0.0;
-    for (int w = c.agg_vw_ptr[g]; w < c.agg_vw_ptr[g + 1]; ++w) s += c.pc_part[(size_t)w * NF + f];
+#pragma unroll 16
+    for (int k = 0; k < c.vw_slots; ++k) s += pp[k];
     pc[t] = s;
   }
   __syncthreads();
   if (row >= n) return;
   double s = 0.0;
-  for (int cc = lane; cc < n; cc += 64) s += c.AciT[(size_t)row * n + cc] * pc[cc];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int cc = lane + 64 * k; if (cc < n) s += a[k] * pc[cc]; }
   s = wave_sum(s);
   if (lane == 0) c.yc[row] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
-// SELL block SpMV: out = A (x + P yc).  One workgroup (4 waves) per slice, the waves split the block
-// columns; lane = (block row in slice, scalar row).  Every value load is a 512-byte contiguous wave read.
+// SELL block SpMV: out = A (x + P yc).  One workgroup (NW waves) per slice, the waves split the block columns;
+// lane = (block row in slice, scalar row).  Every value load is a 504-byte contiguous wave read.
 // MODE 0: plain.  MODE 1: part_a = (rhat, out).  MODE 2: part_b = (out,s) (out,out) (rhat,s) (rhat,out).
 // ---------------------------------------------------------------------------------------------
-template <int NF, int MODE>
-__global__ __launch_bounds__(kVecBlock) void k_spmv(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
+template <int NF, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_spmv(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
   constexpr int S = kWave / NF;
-  __shared__ double red[4][64];
+  __shared__ double red[NW][64];
   if (MODE != 0 && c.scal->done) return;
-  const int s = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int Iloc = lane / NF, i = lane - Iloc * NF;
   const int I = s * S + Iloc;
   const bool active = (Iloc < S) && (I < c.nv);
+  const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
+  const double* base = c.vals + c.slice_off[s] + lane;
+  double rh = 0.0, sv = 0.0;  // operands of the fused dot products: requested early
+  if (MODE != 0 && w == 0 && active) { rh = c.krhat[I * NF + i]; if (MODE == 2) sv = c.ks[I * NF + i]; }
   double acc = 0.0;
   if (active) {
-    const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
-    const double* base = c.vals + c.slice_off[s] + lane;
-    for (int kp = w; kp < mx; kp += 4) {
+#pragma unroll 2
+    for (int kp = w; kp < mx; kp += NW) {
       const int pk = c.sell_cols[(size_t)(cb + kp) * kSlicePad + Iloc];
       const double* xv = x + (size_t)(pk & 0xFFFFFF) * NF;
       const double* yv = c.yc + (pk >> 24) * NF;
@@ -670,14 +679,16 @@ __global__ __launch_bounds__(kVecBlock) void k_spmv(const Ctx c, const double* _
   red[w][lane] = acc;
   __syncthreads();
   if (w != 0) return;
-  const double tot = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  double tot = 0.0;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) tot += red[q][lane];
   const int r = I * NF + i;
   if (active) out[r] = tot;
   if (MODE == 1) {
-    const double d = wave_sum(active ? c.krhat[r] * tot : 0.0);
+    const double d = wave_sum(active ? rh * tot : 0.0);
     if (lane == 0) c.part_a[s] = d;
   } else if (MODE == 2) {
-    const double sv = active ? c.ks[r] : 0.0, rh = active ? c.krhat[r] : 0.0, tv = active ? tot : 0.0;
+    const double tv = active ? tot : 0.0;
     const double d0 = wave_sum(tv * sv), d1 = wave_sum(tv * tv), d2 = wave_sum(rh * sv), d3 = wave_sum(rh * tv);
     if (lane == 0) {
       c.part_b[s] = d0; c.part_b[c.nslices + s] = d1; c.part_b[2 * c.nslices + s] = d2; c.part_b[3 * c.nslices + s] = d3;
@@ -697,22 +708,28 @@ __global__ __launch_bounds__(kVecBlock) void k_spmv(const Ctx c, const double* _
 // ---------------------------------------------------------------------------------------------
 template <int NF>
 __device__ inline void dinv_restrict(const Ctx& c, int wg, int n0, int nnodes, int tid, bool valid, double val,
-                                     double* lv /* [kVecBlock] */) {
+                                     const double (&drow)[NF], double* lv /* [kVecBlock] */) {
   lv[tid] = valid ? val : 0.0;
   __syncthreads();
   if (valid) {
-    const int r = n0 * NF + tid, nl = tid / NF;
-    const double* d = c.Dinv + (size_t)r * NF;
+    const int nl = tid / NF;
     double q = 0.0;
 #pragma unroll
-    for (int mI = 0; mI < NF; ++mI) q += d[mI] * lv[nl * NF + mI];
-    c.kq[r] = q;
+    for (int mI = 0; mI < NF; ++mI) q += drow[mI] * lv[nl * NF + mI];
+    c.kq[n0 * NF + tid] = q;
   }
   if (tid < NF) {
     double s = 0.0;
     for (int nl = 0; nl < nnodes; ++nl) s += lv[nl * NF + tid];
-    c.pc_part[(size_t)wg * NF + tid] = s;
+    const int g = c.vw_agg[wg];
+    c.pc_part[(size_t)(g * NF + tid) * c.vw_slots + (wg - c.agg_vw_ptr[g])] = s;
   }
+}
+
+template <int NF>
+__device__ inline void load_dinv_row(const Ctx& c, int r, bool valid, double (&drow)[NF]) {
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI) drow[mI] = valid ? c.Dinv[(size_t)r * NF + mI] : 0.0;
 }
 
 template <int NF>
@@ -725,34 +742,42 @@ __global__ __launch_bounds__(kVecBlock) void k_vec1(const Ctx c) {
   const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
   const bool valid = tid < nnodes * NF;
   const int r = n0 * NF + tid;
-  const bool first = (sc->iters == 0);
+  const int iters = sc->iters;
+  const bool first = (iters == 0);
+  // every operand is requested before the partial sums are reduced (independent round trips overlap)
+  double drow[NF];
+  load_dinv_row<NF>(c, r, valid, drow);
+  double sv = 0.0, tv = 0.0, pold = 0.0, vv = 0.0, yv = 0.0, r0 = 0.0;
+  if (valid) {
+    if (first) r0 = c.kr[r];
+    else { sv = c.ks[r]; tv = c.kt[r]; pold = c.kp[r]; vv = c.kv[r]; yv = c.ky[r]; }
+  }
   double pv = 0.0, rn = 0.0, rho_next;
   if (first) {
     rho_next = sc->rho;
-    if (valid) { rn = c.kr[r]; pv = rn; }
+    rn = r0; pv = r0;
   } else {
+    const double alpha = sc->alpha, rho = sc->rho;
     double tot[4];
     sum_partials<4>(c.part_b, c.nslices, c.nslices, tot, lred);
     const double ts = tot[0], tt = tot[1], rs = tot[2], rt = tot[3];
-    const double alpha = sc->alpha, rho = sc->rho;
     const double omega = ts / tt;
     rho_next = rs - omega * rt;
     const double beta = (rho_next / rho) * (alpha / omega);
     if (valid) {
-      const double sv = c.ks[r], tv = c.kt[r], pold = c.kp[r];
-      c.ky[r] += alpha * pold + omega * sv;
+      c.ky[r] = yv + alpha * pold + omega * sv;
       rn = sv - omega * tv;
       c.kr[r] = rn;
-      pv = rn + beta * (pold - omega * c.kv[r]);
+      pv = rn + beta * (pold - omega * vv);
     }
   }
   if (valid) c.kp[r] = pv;
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, pv, lv);
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, pv, drow, lv);
   double v[1] = {rn * rn};
   block_sum<1>(v, lred);
   if (tid == 0) {
     c.part_rr[wg] = v[0];
-    if (wg == 0) { sc->rho_next = rho_next; sc->it_cur = first ? 0 : sc->iters; }
+    if (wg == 0) { sc->rho_next = rho_next; sc->it_cur = iters; }
   }
 }
 
@@ -763,29 +788,31 @@ __global__ __launch_bounds__(kVecBlock) void k_vec2(const Ctx c) {
   KrylovScalars* sc = c.scal;
   if (sc->done) return;
   const int wg = blockIdx.x, tid = threadIdx.x;
+  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
+  const bool valid = tid < nnodes * NF;
+  const int r = n0 * NF + tid;
+  // vec2 only reads scalars that vec1 (the previous launch) wrote and only writes scalars that vec1 reads
+  const double rho_next = sc->rho_next, tol = sc->tol;
+  const int iters = sc->it_cur, max_iters = sc->max_iters;
+  double drow[NF];
+  load_dinv_row<NF>(c, r, valid, drow);
+  const double rv_ = valid ? c.kr[r] : 0.0, vv = valid ? c.kv[r] : 0.0;
   double rr[1], rv[1];
   sum_partials<1>(c.part_rr, c.n_vecwg, c.n_vecwg, rr, lred);
   sum_partials<1>(c.part_a, c.nslices, c.nslices, rv, lred);
-  // vec2 only reads scalars that vec1 (the previous launch) wrote and only writes scalars that vec1 reads
-  const double rho_next = sc->rho_next;
-  const int iters = sc->it_cur;
   int done = 0;
   if (!(rr[0] == rr[0]) || !(rv[0] == rv[0])) done = 3;                  // NaN
-  else if (sqrt(rr[0]) <= sc->tol) done = 1;
-  else if (iters >= sc->max_iters) done = 2;
+  else if (sqrt(rr[0]) <= tol) done = 1;
+  else if (iters >= max_iters) done = 2;
   else if (rv[0] == 0.0 || rho_next == 0.0) done = 3;                    // breakdown
   if (done) {
-    // scalars are only written here, after every workgroup has passed its own (identical) test
     if (wg == 0 && tid == 0) { sc->rr = rr[0]; sc->done = done; }
     return;
   }
   const double alpha = rho_next / rv[0];
-  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
-  const bool valid = tid < nnodes * NF;
-  const int r = n0 * NF + tid;
   double sv = 0.0;
-  if (valid) { sv = c.kr[r] - alpha * c.kv[r]; c.ks[r] = sv; }
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, sv, lv);
+  if (valid) { sv = rv_ - alpha * vv; c.ks[r] = sv; }
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, sv, drow, lv);
   if (wg == 0 && tid == 0) { sc->alpha = alpha; sc->rho = rho_next; sc->rr = rr[0]; sc->iters = iters + 1; }
 }
 
@@ -796,7 +823,9 @@ __global__ __launch_bounds__(kVecBlock) void k_vec_final(const Ctx c) {
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
   const bool valid = tid < nnodes * NF;
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, valid ? c.ky[n0 * NF + tid] : 0.0, lv);
+  double drow[NF];
+  load_dinv_row<NF>(c, n0 * NF + tid, valid, drow);
+  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, valid ? c.ky[n0 * NF + tid] : 0.0, drow, lv);
 }
 
 // dst[r] = scale_dst * dst[r] + scale_x * (q[r] + yc[agg]);  Newton update: u -= omega dx  (scale_dst 1, scale_x -omega)

@@ -159,10 +159,12 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   t.agg_vw_ptr.assign(nagg + 1, 0);
   for (int g = 0; g < nagg; ++g) {
     for (int n0 = t.agg_start[g]; n0 < t.agg_start[g + 1]; n0 += npw) {
-      t.vw_node0.push_back(n0); t.vw_node1.push_back(std::min(n0 + npw, t.agg_start[g + 1]));
+      t.vw_node0.push_back(n0); t.vw_node1.push_back(std::min(n0 + npw, t.agg_start[g + 1])); t.vw_agg.push_back(g);
     }
     t.agg_vw_ptr[g + 1] = (int32_t)t.vw_node0.size();
+    t.vw_slots = std::max(t.vw_slots, t.agg_vw_ptr[g + 1] - t.agg_vw_ptr[g]);
   }
+  t.vw_slots = ((t.vw_slots + 15) / 16) * 16;
   return "";
 }
 
