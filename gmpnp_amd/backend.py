@@ -27,7 +27,7 @@ EXPORTS = [
     "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
-    "gmpnp_time_kernel", "gmpnp_spmv_profile",
+    "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library(path: str = None):
     lib.gmpnp_spmv.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_linear_solve.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), c_int32, c_double, c_double,
                                        c_int32, POINTER(CLinearStats)]
+    lib.gmpnp_precond_apply.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
     lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
     if path is None:
@@ -139,6 +140,8 @@ def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -
         axis = axis * np.sign(axis[np.argmax(np.abs(axis))])
         key = X @ axis
     order = np.argsort(key, kind="stable")
+    if not window:
+        return order.astype(np.int32)
     k = cells.shape[1]
     pairs = np.unique(np.repeat(cells, k, axis=1).ravel().astype(np.int64) * nv + np.tile(cells, (1, k)).ravel())
     deg = np.bincount((pairs // nv).astype(np.int64), minlength=nv)
@@ -312,6 +315,13 @@ class DeviceSolver:
         self._check(code)
         return x, {"iterations": st.iterations, "converged": bool(st.converged), "residual_norm": st.residual_norm,
                    "rhs_norm": st.rhs_norm}
+
+    def precond_apply(self, r, linear_solver=LINEAR_TWOLEVEL):
+        """z = M^{-1} r with the preconditioner of the current device Jacobian."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty(self.ndof)
+        self._check(self.lib.gmpnp_precond_apply(self._h, linear_solver, _dptr(r), _dptr(z)))
+        return z
 
     def newton_solve(self, options: CNewtonOptions, error_on_nonconvergence=True):
         """``solve(F == 0, u, bcs, solver_parameters)`` on the device state.  Raises RuntimeError on

@@ -673,7 +673,7 @@ int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->model = *model;
   HIP_TRY(hipMemcpy(s->d_model.p, &s->model, sizeof(gmpnp_model_t), hipMemcpyHostToDevice));
-  s->jacobian_valid = false;
+  s->jacobian_valid = false; s->precond_valid = false;
   return rebuild_boundary(s);
 }
 
@@ -829,6 +829,27 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->tmpx.p, 0.0, 1.0)));
   if (rc) return rc;
   return download_vec(s, s->tmpx.p, x);
+}
+
+int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* z) {
+  if (!s || !r || !z) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
+    return fail(GMPNP_ERR_INVALID, "preconditioner kinds: two-level or Jacobi");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  int rc;
+  if (!s->precond_valid || s->precond_mode != mode) {
+    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+    GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*s->h_status & 6) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
+  }
+  rc = upload_vec(s, r, s->ky.p); if (rc) return rc;
+  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->tmpx.p, 0.0, 1.0)));
+  if (rc) return rc;
+  return download_vec(s, s->tmpx.p, z);
 }
 
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {

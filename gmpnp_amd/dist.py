@@ -1,0 +1,328 @@
+"""Mesh-partitioned Newton solve across ranks: one process per GPU, `torch.distributed` for the ghost
+exchange and the scalar all-reduces (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference is a serial script (no MPI call site), so there is no behaviour to match except the serial result
+itself: the partitioned solve must give the serial Newton iterates.
+
+Decomposition.  Vertices are ordered by `backend.slab_permutation` (slabs along the pore axis) and cut into P
+contiguous ranges: rank p OWNS its range.  Its local mesh is every cell that touches an owned vertex; the other
+vertices of those cells are GHOSTS (owned by a neighbouring slab).  Cut cells are assembled redundantly on both sides,
+so the rows of owned vertices are complete without any matrix communication; ghost rows are replaced by identity rows
+(they are never used).  Communication per Newton iteration: one ghost exchange of u; per Krylov iteration: two ghost
+exchanges (one per operator application) and the BiCGStab scalars as fused all-reduces of 5 / 2 doubles.
+
+The Krylov loop runs on the host in this module (right-preconditioned BiCGStab, same recurrences as the device
+solver), calling the rank's backend for the three local operations: assemble, y = A_local x, z = M_local^{-1} r
+(subdomain node-block Jacobi + slab coarse correction: an additive Schwarz preconditioner with minimal overlap).
+On a 3.7k-vertex mesh this cannot beat one GPU — an RCCL small-message all-reduce costs more than the local SpMV — and
+the per-call host copies of this first version dominate; the mapping that scales is one problem per GPU (bench.py).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+
+import numpy as np
+
+from .problem import Problem
+
+
+# ---------------------------------------------------------------------------------------------
+# partition
+# ---------------------------------------------------------------------------------------------
+def slab_owner(coords: np.ndarray, cells: np.ndarray, nparts: int) -> np.ndarray:
+    """owner[vertex] for `nparts` equal-count slabs of the slab order (the order the solver uses internally)."""
+    from .backend import slab_permutation
+    perm = slab_permutation(coords, cells, window=0)  # pure slab order: sharp partition interfaces
+    owner = np.empty(coords.shape[0], dtype=np.int32)
+    nv = coords.shape[0]
+    for p in range(nparts):
+        owner[perm[(nv * p) // nparts:(nv * (p + 1)) // nparts]] = p
+    return owner
+
+
+@dataclass
+class LocalDomain:
+    rank: int
+    nparts: int
+    owned: np.ndarray  # global (file) vertex ids, ascending
+    ghosts: np.ndarray  # global vertex ids, ascending
+    ghost_owner: np.ndarray  # rank owning each ghost
+    problem: Problem  # local problem: vertices = [owned..., ghosts...]
+    n_owned: int
+    send: dict  # neighbour rank -> local indices (into owned) to send, in the receiver's ghost order
+    recv: dict  # neighbour rank -> local indices (n_owned + k) that receive
+
+    @property
+    def nf(self):
+        return self.problem.nf
+
+    def owned_dofs(self):
+        return slice(0, self.n_owned * self.nf)
+
+
+def build_local_domain(prob: Problem, owner: np.ndarray, rank: int, nparts: int) -> LocalDomain:
+    """Local problem of `rank`.  Deterministic and purely local (every rank can build any rank's domain), so the
+    send lists need no negotiation: rank q's ghosts owned by p, in ascending global id, are what p sends to q."""
+    nf = prob.nf
+    cells = prob.cells
+    touch = (owner[cells] == rank).any(axis=1)
+    lcells = cells[touch]
+    verts = np.unique(lcells)
+    owned = verts[owner[verts] == rank]
+    ghosts = verts[owner[verts] != rank]
+    all_owned = np.nonzero(owner == rank)[0]
+    assert np.array_equal(owned, all_owned), "every owned vertex must belong to a local cell"
+    lverts = np.concatenate([owned, ghosts])
+    g2l = -np.ones(prob.coords.shape[0], dtype=np.int64)
+    g2l[lverts] = np.arange(len(lverts))
+
+    def facets_local(fv):
+        if len(fv) == 0:
+            return np.zeros((0, 3), dtype=np.int32)
+        keep = (owner[fv] == rank).any(axis=1)
+        return g2l[fv[keep]].astype(np.int32)
+
+    # Dirichlet: the global conditions restricted to local vertices + identity rows on every ghost dof
+    gv = prob.bc_dofs // nf
+    inloc = g2l[gv] >= 0
+    ldofs = g2l[gv[inloc]] * nf + prob.bc_dofs[inloc] % nf
+    lvals = prob.bc_vals[inloc]
+    gh_dofs = (np.arange(len(owned), len(lverts))[:, None] * nf + np.arange(nf)[None, :]).ravel()
+    table = dict(zip(ldofs.tolist(), lvals.tolist()))
+    for d in gh_dofs.tolist():
+        table[d] = 0.0  # value irrelevant: ghost rows are never used
+    bd = np.array(sorted(table), dtype=np.int64)
+    bvl = np.array([table[d] for d in bd])
+    pv = prob.point_vertices
+    pv_local = g2l[pv[owner[pv] == rank]].astype(np.int32) if len(pv) else np.zeros(0, dtype=np.int32)
+    local = Problem(coords=prob.coords[lverts], cells=g2l[lcells].astype(np.int32), model=prob.model, quad=prob.quad,
+                    wall_facets=facets_local(prob.wall_facets), exit_facets=facets_local(prob.exit_facets),
+                    point_vertices=pv_local, bc_dofs=bd, bc_vals=bvl)
+    # halo plan
+    send, recv = {}, {}
+    gowner = owner[ghosts]
+    for q in np.unique(gowner):
+        recv[int(q)] = len(owned) + np.nonzero(gowner == q)[0]
+    for q in range(nparts):
+        if q == rank:
+            continue
+        tq = (owner[cells] == q).any(axis=1)
+        vq = np.unique(cells[tq])
+        mine = vq[owner[vq] == rank]  # ascending global id == q's ghost order restricted to my vertices
+        if len(mine):
+            send[q] = g2l[mine]
+    return LocalDomain(rank=rank, nparts=nparts, owned=owned, ghosts=ghosts, ghost_owner=gowner, problem=local,
+                       n_owned=len(owned), send=send, recv=recv)
+
+
+# ---------------------------------------------------------------------------------------------
+# communication
+# ---------------------------------------------------------------------------------------------
+class Comm:
+    """Thin wrapper over torch.distributed (or a serial no-op) working on numpy vectors."""
+
+    def __init__(self, dom: LocalDomain, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.dom = dom
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.device = device if device is not None else "cpu"
+
+    def allreduce_sum(self, values):
+        a = np.asarray(values, dtype=np.float64)
+        if not self.active:
+            return a.copy()
+        t = self.torch.from_numpy(a.copy()).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def exchange(self, x):
+        """Overwrite the ghost entries of the local vector x (n_local*nf) with the owners' values."""
+        if not self.active:
+            return x
+        nf = self.dom.nf
+        x2 = x.reshape(-1, nf)
+        ops, bufs = [], []
+        for q, idx in sorted(self.dom.send.items()):
+            t = self.torch.from_numpy(np.ascontiguousarray(x2[idx])).to(self.device)
+            ops.append(self.dist.P2POp(self.dist.isend, t, q))
+        for q, idx in sorted(self.dom.recv.items()):
+            t = self.torch.empty((len(idx), nf), dtype=self.torch.float64, device=self.device)
+            bufs.append((idx, t))
+            ops.append(self.dist.P2POp(self.dist.irecv, t, q))
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()
+        for idx, t in bufs:
+            x2[idx] = t.cpu().numpy()
+        return x
+
+
+# ---------------------------------------------------------------------------------------------
+# local operations on the device (the CPU tests substitute a test double with the same three methods)
+# ---------------------------------------------------------------------------------------------
+class DeviceLocalOps:
+    def __init__(self, dom: LocalDomain, linear_solver=0, **device_kwargs):
+        from . import backend
+        self.backend = backend
+        self.dev = backend.DeviceSolver(dom.problem, **device_kwargs)
+        self.mode = linear_solver
+
+    def assemble(self, u, un, want_jacobian):
+        self.dev.set_state(u, un)
+        F, _ = self.dev.assemble(want_jacobian)
+        return F
+
+    def spmv(self, x):
+        return self.dev.spmv(x)
+
+    def precond(self, r):
+        return self.dev.precond_apply(r, self.mode)
+
+    def close(self):
+        self.dev.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# distributed BiCGStab + Newton
+# ---------------------------------------------------------------------------------------------
+def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=10000):
+    """Right-preconditioned BiCGStab on the owned dofs; returns (x_local incl. ghosts, iterations, converged)."""
+    own = dom.owned_dofs()
+    n = len(b)
+
+    def dots(pairs):
+        return comm.allreduce_sum([float(np.dot(a[own], c[own])) for a, c in pairs])
+
+    def apply(p):
+        """A M^{-1} p on owned rows (ghost entries of the result are zeroed)."""
+        pin = p.copy()
+        pin[own.stop:] = 0.0
+        z = ops.precond(pin)
+        z[own.stop:] = 0.0
+        comm.exchange(z)
+        y = ops.spmv(z)
+        y[own.stop:] = 0.0
+        return y, z
+
+    r = b.copy()
+    r[own.stop:] = 0.0
+    rhat = r.copy()
+    bnorm = np.sqrt(dots([(r, r)])[0])
+    tol = max(rtol * bnorm, atol)
+    y = np.zeros(n)
+    if not bnorm > 0.0:
+        return np.zeros(n), 0, True
+    rho = bnorm * bnorm
+    p = r.copy()
+    it = 0
+    tiny = np.finfo(np.float64).tiny
+
+    def restart():
+        """BiCGStab breakdown ((rhat,v) ~ 0 or omega ~ 0): true residual, new shadow vector."""
+        nonlocal r, rhat, p, rho
+        Ay, _ = apply(y)
+        r = b - Ay
+        r[own.stop:] = 0.0
+        rhat = r.copy()
+        p = r.copy()
+        rho = dots([(r, r)])[0]
+        return np.sqrt(rho) <= tol
+
+    while True:
+        if it >= maxit:
+            return None, it, False
+        v, _ = apply(p)
+        rv = dots([(rhat, v)])[0]
+        if abs(rv) <= 1e-14 * abs(rho) or abs(rho) <= tiny:
+            it += 1
+            if restart():
+                break
+            continue
+        alpha = rho / rv
+        s = r - alpha * v
+        if np.sqrt(dots([(s, s)])[0]) <= tol:  # converged at the half step (exact subdomain solves get here)
+            y += alpha * p
+            it += 1
+            break
+        t, _ = apply(s)
+        ts, tt, rs, rt = dots([(t, s), (t, t), (rhat, s), (rhat, t)])
+        omega = ts / tt
+        y += alpha * p + omega * s
+        r = s - omega * t
+        it += 1
+        rr = dots([(r, r)])[0]
+        if np.sqrt(rr) <= tol:
+            break
+        rho_new = rs - omega * rt
+        if abs(omega) <= 1e-14 or abs(rho_new) <= 1e-14 * abs(rho) * abs(omega):
+            if restart():
+                break
+            continue
+        beta = (rho_new / rho) * (alpha / omega)
+        p = r + beta * (p - omega * v)
+        rho = rho_new
+    yin = y.copy()
+    yin[own.stop:] = 0.0
+    x = ops.precond(yin)
+    x[own.stop:] = 0.0
+    comm.exchange(x)
+    return x, it, True
+
+
+def newton_solve(ops, comm: Comm, dom: LocalDomain, u, un, maximum_iterations=50, relative_tolerance=1e-4,
+                 absolute_tolerance=1e-4, relaxation_parameter=1.0, krylov_rtol=1e-10, krylov_maxit=10000,
+                 error_on_nonconvergence=True):
+    """[3P] dolfin::NewtonSolver semantics on a partitioned state; u, un are local (owned+ghost)."""
+    own = dom.owned_dofs()
+    u = comm.exchange(u.copy())
+    un = comm.exchange(un.copy())
+
+    def residual(want_j):
+        F = ops.assemble(u, un, want_j)
+        F[own.stop:] = 0.0
+        return F, float(np.sqrt(comm.allreduce_sum([float(np.dot(F[own], F[own]))])[0]))
+
+    stats = {"iterations": 0, "residuals": [], "krylov_per_iteration": [], "converged": False}
+    b, r = residual(False)
+    r0 = r
+    stats["residuals"].append(r)
+
+    def conv(res):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = np.float64(res) / np.float64(r0)
+        return bool(rel < relative_tolerance or res < absolute_tolerance)
+
+    done = conv(r)
+    while not done and stats["iterations"] < maximum_iterations:
+        b, _ = residual(True)
+        dx, kits, ok = bicgstab(ops, comm, dom, b, rtol=krylov_rtol, maxit=krylov_maxit)
+        if not ok:
+            raise RuntimeError("distributed BiCGStab did not converge (%d iterations)" % kits)
+        stats["krylov_per_iteration"].append(kits)
+        u = u - relaxation_parameter * dx
+        stats["iterations"] += 1
+        b, r = residual(False)
+        stats["residuals"].append(r)
+        done = conv(r)
+    stats["converged"] = done
+    if not done and error_on_nonconvergence:
+        raise RuntimeError("Newton solver did not converge because maximum number of iterations reached")
+    return u, stats
+
+
+def gather_global(comm: Comm, dom: LocalDomain, u_local, nv_global):
+    """Assemble the global (file-order) state on every rank from the owned parts (all-reduce of disjoint pieces)."""
+    nf = dom.nf
+    out = np.zeros(nv_global * nf)
+    o2 = out.reshape(nv_global, nf)
+    o2[dom.owned] = u_local.reshape(-1, nf)[:dom.n_owned]
+    return comm.allreduce_sum(out) if comm.active else out
+
+
+def scatter_local(dom: LocalDomain, u_global):
+    nf = dom.nf
+    lverts = np.concatenate([dom.owned, dom.ghosts])
+    return u_global.reshape(-1, nf)[lverts].ravel().copy()

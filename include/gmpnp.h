@@ -187,6 +187,11 @@ int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y);
 int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t linear_solver, double rtol,
                        double atol, int32_t max_iterations, gmpnp_linear_stats_t* stats);
 
+/* z = M^{-1} r with the preconditioner of the current device Jacobian (node-block Jacobi [+ coarse correction]);
+ * the first call after an assembly builds it.  Used by the partitioned multi-GPU driver (gmpnp_amd/dist.py), where
+ * the Krylov loop runs across ranks and each rank applies its subdomain preconditioner. */
+int gmpnp_precond_apply(gmpnp_solver* s, int32_t linear_solver, const double* r, double* z);
+
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
  * events; kernel: 0 = Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather. */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);

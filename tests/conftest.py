@@ -70,3 +70,42 @@ def gpu_lib():
     ge.build()
     from gmpnp_amd import backend
     return backend
+
+
+def box_pore_problem(nx=4, nz=12, half_width=0.1):
+    """Small synthetic 'pore': the box [-w,w]^2 x [0,1] cut into 6 tetrahedra per cell, with the 3D pore model,
+    ds(2) = lateral faces, ds(3) = the z=1 face and the reference's Dirichlet pattern (3D:460-467).  Used where the
+    reference meshes are too large for a CPU test (sparse LU of a 3D Jacobian takes ~10 s on them)."""
+    from gmpnp_amd.mesh import Mesh
+    from gmpnp_amd.params import pore_parameters
+    from gmpnp_amd.problem import Problem, merge_dirichlet
+    pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
+    xs = np.linspace(-half_width, half_width, nx + 1)
+    zs = np.linspace(0.0, 1.0, nz + 1)
+    X, Y, Z = np.meshgrid(xs, xs, zs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    idx = np.arange(coords.shape[0]).reshape(nx + 1, nx + 1, nz + 1)
+    cells = []
+    for i in range(nx):
+        for j in range(nx):
+            for k in range(nz):
+                v = [idx[i + a, j + b, k + c] for a in (0, 1) for b in (0, 1) for c in (0, 1)]  # v[4a+2b+c]
+                for t in ((0, 1, 3, 7), (0, 1, 5, 7), (0, 2, 3, 7), (0, 2, 6, 7), (0, 4, 5, 7), (0, 4, 6, 7)):
+                    cells.append([v[q] for q in t])
+    mesh = Mesh(dim=3, coords=coords, cells=np.array(cells, dtype=np.int32))
+    fv, ext, _ = mesh.facets()
+    P = coords[fv]
+    on = lambda test: ext & test(P).all(axis=1)  # noqa: E731
+    lateral = on(lambda p: (np.abs(np.abs(p[..., 0]) - half_width) < 1e-12)) | on(lambda p: (np.abs(np.abs(p[..., 1]) - half_width) < 1e-12))
+    entry, exit_ = on(lambda p: np.abs(p[..., 2]) < 1e-12), on(lambda p: np.abs(p[..., 2] - 1.0) < 1e-12)
+    s1, s2, s3 = np.unique(fv[entry]), np.unique(fv[lateral]), np.unique(fv[exit_])
+    dofs, vals = merge_dirichlet([(s1, 8, 0.0), (s3, 8, 0.0), (s2, 8, pp.voltage_scaled), (s1, 4, pp.eq_conc_CO2_scaled),
+                                  (s1, 5, pp.eq_conc_CO_scaled), (s1, 6, pp.eq_conc_H2_scaled)], 9)
+    prob = Problem(coords=coords, cells=mesh.cells, model=pp.model, wall_facets=fv[lateral], exit_facets=fv[exit_],
+                   bc_dofs=dofs, bc_vals=vals)
+    return pp, mesh, prob
+
+
+@pytest.fixture(scope="session")
+def boxpore():
+    return box_pore_problem()

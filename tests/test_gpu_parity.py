@@ -312,3 +312,55 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     m1 = json.load(open(os.path.join(out1, "metadata.json")))
     assert {"eps_rel_OHP", "field_OHP", "pH_OHP", "CO2_OHP_frac", "mesh_number", "mesh_structure"} <= set(m1)
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
+
+
+def _partition_worker(rank, world, port, out_dir):
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of the test box
+    try:
+        from gmpnp_amd import dist
+        from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+        from gmpnp_amd.params import pore_parameters, utilities_dir
+        from gmpnp_amd.problem import pore_problem
+        pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
+        mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+        prob, _ = pore_problem(pp, mesh)
+        nv = mesh.num_vertices
+        owner = dist.slab_owner(prob.coords, prob.cells, world)
+        dom = dist.build_local_domain(prob, owner, rank, world)
+        comm = dist.Comm(dom)
+        ops = dist.DeviceLocalOps(dom)
+        try:
+            un = np.tile(np.r_[np.ones(8), 0.0], nv)
+            u, st = dist.newton_solve(ops, comm, dom, dist.scatter_local(dom, np.zeros(nv * 9)),
+                                      dist.scatter_local(dom, un), relaxation_parameter=0.9, krylov_rtol=1e-11)
+            ug = dist.gather_global(comm, dom, u, nv)
+        finally:
+            ops.close()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "dist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
+                     kits=np.array(st["krylov_per_iteration"]))
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_partitioned_solve_matches_serial(tmp_path, gpu_lib):
+    """Two ranks (two processes on this box's single GPU, gloo for the exchange): mesh-partitioned Newton solve with the
+    HIP backend doing the local assembly / SpMV / subdomain preconditioner = the serial result (golden pore10 step 0)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_partition_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "dist.npz"))
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    assert int(got["its"]) == int(g["newton_its"][0])
+    assert np.allclose(got["res"], g["residuals"][0][:len(got["res"])], rtol=1e-5)
+    assert relerr(got["u"], g["states"][0]) < 1e-7
