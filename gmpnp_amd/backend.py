@@ -127,8 +127,8 @@ def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -
 
     Vertices are sorted along the principal axis of the point cloud (for the pore: z), so contiguous
     ranges are slabs — they become the coarse-space aggregates of the two-level preconditioner and the
-    per-GPU partitions.  Inside windows of ``window`` vertices the order is then stably re-sorted by
-    decreasing node degree, which makes the rows of one SELL slice equally long (padding < 2 %)."""
+    per-GPU partitions.  The library re-sorts by node degree INSIDE each aggregate itself (SELL padding), so the
+    default is ``window=0``; a non-zero ``window`` applies that degree sort here in windows of that many vertices."""
     nv = coords.shape[0]
     X = coords - coords.mean(axis=0)
     if coords.shape[1] == 1:
@@ -195,7 +195,7 @@ class DeviceSolver:
         self._coords = np.ascontiguousarray(problem.coords, dtype=np.float64)
         self._cells = np.ascontiguousarray(problem.cells, dtype=np.int32)
         self.perm = np.ascontiguousarray(
-            slab_permutation(self._coords, self._cells) if perm is None else perm, dtype=np.int32)
+            slab_permutation(self._coords, self._cells, window=0) if perm is None else perm, dtype=np.int32)
         self._wall = np.ascontiguousarray(problem.wall_facets, dtype=np.int32).reshape(-1, 3)
         self._exit = np.ascontiguousarray(problem.exit_facets, dtype=np.int32).reshape(-1, 3)
         self._pts = np.ascontiguousarray(problem.point_vertices, dtype=np.int32)

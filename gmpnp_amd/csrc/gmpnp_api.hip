@@ -8,10 +8,6 @@
 #include <cstring>
 #include <memory>
 
-#ifndef GMPNP_SPMV_WAVES
-#define GMPNP_SPMV_WAVES 8
-#endif
-
 #include "gmpnp_kernels.h"
 
 using namespace gmpnp;
@@ -70,10 +66,12 @@ struct gmpnp_solver {
   std::vector<int32_t> wall_f, exit_f, point_v;
   // device storage
   DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
-  DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, Dinv, AP, AcPart, Ac, AciT;
-  DevBuf<double> kr, krhat, kp, kv, ks, kt, ky, kq, pc_part, yc, part_rr, part_a, part_b, part_f, tmpx;
+  DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, vals_s, Dinv, AP, AcPart, Ac, Aci;
+  DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
+      part_rr, part_a, part_b, part_f;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
-      sell_cols, sell_blk, wl_slice, wl_kpos, vw_agg, agg, agg_start, row_aggs, vw_node0, vw_node1, agg_vw_ptr, status;
+      slice_node0, slice_nn, node_slice, sell_cols, sell_blk, wl_slice, wl_kpos, tile_slice0, tile_agg, tile_slot,
+      tile_aggs, tile_nagg, tile_colptr, tile_cols, tile_colslot, sell_lcol, agg, agg_start, row_aggs, status;
   DevBuf<int64_t> rob_addr, slice_off;
   DevBuf<uint8_t> bcflag, sell_aggslot;
   DevBuf<KrylovScalars> scal;
@@ -115,8 +113,6 @@ namespace {
     else if ((s)->dim == 1 && (s)->nf == 7) { constexpr int DIM = 1, NF = 7; CALL; } \
     else return fail(GMPNP_ERR_INVALID, "unsupported (dim, n_fields)"); \
   } while (0)
-
-constexpr int kSpmvWaves = GMPNP_SPMV_WAVES;  // waves per SELL slice in k_spmv
 
 int grid_for(int n, int block) { return (n + block - 1) / block; }
 
@@ -168,7 +164,7 @@ int rebuild_boundary(gmpnp_solver* s) {
     const int I = row / nf, i = row % nf, J = col / nf, jf = col % nf;
     const int32_t* b = t.cols.data() + t.rowptr[I]; const int32_t* e = t.cols.data() + t.rowptr[I + 1];
     const int kpos = t.sellk[(int)(std::lower_bound(b, e, J) - t.cols.data())];
-    const int sl = I / t.S, il = I - sl * t.S;
+    const int sl = t.node_slice[I], il = I - t.slice_node0[sl];
     rrow.push_back(row); rcol.push_back(col); rval.push_back(v);
     raddr.push_back(t.slice_off[sl] + (int64_t)(kpos * nf + jf) * kWave + il * nf + i);
     rptr[row + 1]++;
@@ -237,8 +233,10 @@ int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
 
 template <int DIM, int NF>
 int setup_preconditioner(gmpnp_solver* s, int mode) {
+  s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 64)), dim3(64), 0, s->stream, s->c);
-  if (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) {
+  hipLaunchKernelGGL((k_scale_columns<NF>), dim3(grid_for(s->c.n_work * kWave, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
+  if (s->c.use_coarse) {
     hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
     hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, s->stream, s->c);
     const int n = s->ncoarse;
@@ -250,17 +248,26 @@ int setup_preconditioner(gmpnp_solver* s, int mode) {
   return GMPNP_OK;
 }
 
-template <int NF, int MODE>
-int launch_spmv(gmpnp_solver* s, const double* x, double* out, bool sample) {
+// One launch of a fused half-iteration, optionally bracketed by events (eager mode sampling).
+template <int NF, int WHICH>
+int launch_half(gmpnp_solver* s, int k, bool sample) {
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if (sample) {
     if (s->ev_used == s->ev_pool.size()) {
       hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); s->ev_pool.push_back({a, b});
     }
     ev = &s->ev_pool[s->ev_used++];
-    HIP_TRY(hipEventRecord(ev->first, s->stream));
   }
-  hipLaunchKernelGGL((k_spmv<NF, MODE, kSpmvWaves>), dim3(s->t.nslices), dim3(kSpmvWaves * 64), 0, s->stream, s->c, x, out);
+  const dim3 cg(grid_for(s->ncoarse, kCoarseThreads / 64));
+  if (WHICH == 0) {
+    hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+    if (ev) HIP_TRY(hipEventRecord(ev->first, s->stream));
+    hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+  } else {
+    hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+    if (ev) HIP_TRY(hipEventRecord(ev->first, s->stream));
+    hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+  }
   if (ev) HIP_TRY(hipEventRecord(ev->second, s->stream));
   s->spmv_launched++;
   return GMPNP_OK;
@@ -276,60 +283,45 @@ int drain_spmv_events(gmpnp_solver* s) {
   return GMPNP_OK;
 }
 
+// Iteration k of the solve (k = 0, 1, ...): the index is a kernel ARGUMENT, so no kernel has to read it back from
+// memory before it can address its parity buffers.
 template <int NF>
-int enqueue_iteration(gmpnp_solver* s, int use_coarse, bool allow_sampling) {
+int enqueue_iteration(gmpnp_solver* s, int k, bool allow_sampling) {
   const int every = s->opts.profile_every;
-  const dim3 cg(grid_for(s->ncoarse, 4)), cb(kVecBlock);
-  hipLaunchKernelGGL((k_vec1<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), cg, cb, 0, s->stream, s->c, use_coarse);
-  int rc = launch_spmv<NF, 1>(s, s->kq.p, s->kv.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
+  int rc = launch_half<NF, 0>(s, k, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_vec2<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), cg, cb, 0, s->stream, s->c, use_coarse);
-  rc = launch_spmv<NF, 2>(s, s->kq.p, s->kt.p, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
-  return rc;
+  return launch_half<NF, 1>(s, k, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
 }
 
-// Solve J dx = rhs (rhs already in c.kr on the device, ||rhs|| = bnorm) with right-preconditioned BiCGStab;
-// leaves y in c.ky; the caller applies M^{-1}.
+// Solve J dx = rhs (rhs already in c.kr on the device, ||rhs|| = bnorm) with the fused right-preconditioned BiCGStab;
+// leaves y in c.ky; the caller applies M^{-1} (apply_minv).
 template <int NF>
 int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  s->c.use_coarse = use_coarse;
   const int n = s->ndof;
-  // rhat = r ; y = 0
   hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr, s->kr.p, n);
   HIP_TRY(hipMemsetAsync(s->ky.p, 0, n * sizeof(double), s->stream));
+  if (use_coarse)  // P^T b partials where A(0) expects them
+    hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->kr.p, s->cpart_v1.p);
   KrylovScalars init{};
-  init.rho = bnorm * bnorm; init.rho_next = init.rho; init.alpha = 1.0;
-  init.tol = std::max(rtol * bnorm, atol); init.rr = init.rho; init.iters = 0; init.max_iters = maxit; init.done = 0;
+  init.rho[0] = init.rho[1] = bnorm * bnorm; init.alpha = 1.0;
+  init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.iters = 0; init.it_cur = 0;
+  init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
   s->h_scal[0] = init;
   HIP_TRY(hipMemcpyAsync(s->scal.p, s->h_scal, sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));  // h_scal is reused for read-back below
-  const bool use_graph = (s->opts.use_graph != 2) && s->opts.profile_every == 0;
   const int B = s->graph_iters;
-  if (use_graph && !s->graph[use_coarse]) {
-    hipGraph_t g;
-    HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int rc = GMPNP_OK;
-    for (int it = 0; it < B && rc == GMPNP_OK; ++it) rc = enqueue_iteration<NF>(s, use_coarse, false);
-    hipError_t e = hipStreamEndCapture(s->stream, &g);
-    if (rc) return rc;
-    HIP_TRY(e);
-    HIP_TRY(hipGraphInstantiate(&s->graph[use_coarse], g, nullptr, nullptr, 0));
-    HIP_TRY(hipGraphDestroy(g));
-  }
   // Bursts of B iterations.  The first burst is 3/4 of what the previous solve with this preconditioner
   // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
   // next burst, then wait for the event), so the read-back latency hides behind queued work.  Kernels of a
   // converged solve exit at their first instruction.
   int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, (3 * s->last_krylov_iters[use_coarse]) / 4);
   first = ((first + B - 1) / B) * B;
+  int next_k = 0;  // iteration index of the next launch (the device stops advancing once `done` is set)
   auto burst = [&](int iters) -> int {
-    for (int k = 0; k < iters; k += B) {
-      if (use_graph) HIP_TRY(hipGraphLaunch(s->graph[use_coarse], s->stream));
-      else for (int it = 0; it < B; ++it) { int rc = enqueue_iteration<NF>(s, use_coarse, true); if (rc) return rc; }
-    }
+    for (int it = 0; it < iters; ++it) { int rc = enqueue_iteration<NF>(s, next_k++, true); if (rc) return rc; }
     return GMPNP_OK;
   };
   KrylovScalars res = init;
@@ -362,14 +354,14 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   return GMPNP_OK;
 }
 
-// x = M^{-1} y applied into dst: dst = scale_dst*dst + scale_x*x
+// dst = scale_dst*dst + scale_x * M^{-1} src,  M^{-1} = Dinv (I + P Aci P^T)
 template <int NF>
-int apply_minv(gmpnp_solver* s, int mode, double* dst, double scale_dst, double scale_x) {
-  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
-  HIP_TRY(hipMemsetAsync(&s->scal.p->done, 0, sizeof(int32_t), s->stream));  // k_coarse honours the flag
-  hipLaunchKernelGGL((k_vec_final<NF>), dim3(s->c.n_vecwg), dim3(kVecBlock), 0, s->stream, s->c);
-  hipLaunchKernelGGL((k_coarse<NF>), dim3(grid_for(s->ncoarse, 4)), dim3(kVecBlock), 0, s->stream, s->c, use_coarse);
-  hipLaunchKernelGGL((k_apply<NF>), dim3(grid_for(s->ndof, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c, dst, scale_dst, scale_x);
+int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x) {
+  s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  if (s->c.use_coarse)
+    hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, src, s->cpart_v0.p);
+  hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, src,
+                     (const double*)s->cpart_v0.p, dst, scale_dst, scale_x);
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
 }
@@ -492,7 +484,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
         return rc;
       }
       // x <- x - omega dx
-      rc = apply_minv<NF>(s, o.linear_solver, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
+      rc = apply_minv<NF>(s, o.linear_solver, s->ky.p, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
     st.iterations++;
@@ -601,7 +593,6 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   const int nv = t.nv, nc = t.nc, nn = s->nn, ndof = s->ndof;
   const int ej_stride = (mesh->dim == 3) ? Lay<3, 9>::EJ_STRIDE : Lay<1, 7>::EJ_STRIDE;
   s->n_resblocks = grid_for(ndof, kVecBlock);
-  const int n_vecwg = (int)t.vw_node0.size();
   std::vector<gmpnp_model_t> mv(1, s->model); std::vector<gmpnp_quadrature_t> qv(1, s->quad);
   HIP_TRY(s->d_model.upload(mv)); HIP_TRY(s->d_quad.upload(qv));
   HIP_TRY(s->coords.upload(t.coords)); HIP_TRY(s->cells.upload(t.cells));
@@ -612,20 +603,26 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->n2e_ptr.upload(t.n2e_ptr)); HIP_TRY(s->n2e.upload(t.n2e));
   HIP_TRY(s->rowptr.upload(t.rowptr)); HIP_TRY(s->cols.upload(t.cols));
   HIP_TRY(s->cptr.upload(t.cptr)); HIP_TRY(s->contrib.upload(t.contrib));
-  HIP_TRY(s->vals.alloc((size_t)t.slice_off[t.nslices]));
+  HIP_TRY(s->vals.alloc((size_t)t.slice_off[t.nslices])); HIP_TRY(s->vals_s.alloc((size_t)t.slice_off[t.nslices]));
   HIP_TRY(s->slice_off.upload(t.slice_off)); HIP_TRY(s->slice_colbase.upload(t.slice_colbase));
+  HIP_TRY(s->slice_node0.upload(t.slice_node0)); HIP_TRY(s->slice_nn.upload(t.slice_nn)); HIP_TRY(s->node_slice.upload(t.node_slice));
   HIP_TRY(s->sell_cols.upload(t.sell_cols)); HIP_TRY(s->sell_aggslot.upload(t.sell_aggslot));
   HIP_TRY(s->wl_slice.upload(t.wl_slice)); HIP_TRY(s->wl_kpos.upload(t.wl_kpos));
   HIP_TRY(s->sell_blk.upload(t.sell_blk));
+  HIP_TRY(s->tile_slice0.upload(t.tile_slice0)); HIP_TRY(s->tile_agg.upload(t.tile_agg)); HIP_TRY(s->tile_slot.upload(t.tile_slot));
+  HIP_TRY(s->tile_aggs.upload(t.tile_aggs)); HIP_TRY(s->tile_nagg.upload(t.tile_nagg));
+  HIP_TRY(s->tile_colptr.upload(t.tile_colptr)); HIP_TRY(s->tile_cols.upload(t.tile_cols));
+  HIP_TRY(s->tile_colslot.upload(t.tile_colslot)); HIP_TRY(s->sell_lcol.upload(t.sell_lcol));
   HIP_TRY(s->Dinv.alloc((size_t)nv * nf * nf));
   HIP_TRY(s->agg.upload(t.agg)); HIP_TRY(s->agg_start.upload(t.agg_start)); HIP_TRY(s->row_aggs.upload(t.row_aggs));
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
-  HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->AciT.alloc((size_t)s->ncoarse * s->ncoarse));
-  HIP_TRY(s->vw_node0.upload(t.vw_node0)); HIP_TRY(s->vw_node1.upload(t.vw_node1)); HIP_TRY(s->agg_vw_ptr.upload(t.agg_vw_ptr)); HIP_TRY(s->vw_agg.upload(t.vw_agg));
-  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp, &s->kv, &s->ks, &s->kt, &s->ky, &s->kq, &s->tmpx}) HIP_TRY(b->alloc(ndof));
-  HIP_TRY(s->pc_part.alloc((size_t)s->ncoarse * t.vw_slots)); HIP_TRY(s->yc.alloc(kMaxCoarse));
-  HIP_TRY(s->part_rr.alloc(n_vecwg)); HIP_TRY(s->part_a.alloc(t.nslices)); HIP_TRY(s->part_b.alloc((size_t)4 * t.nslices));
+  HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
+  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx}) HIP_TRY(b->alloc(ndof));
+  HIP_TRY(s->yc.alloc(kMaxCoarse));
+  for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
+    HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
+  HIP_TRY(s->part_rr.alloc(t.ntiles)); HIP_TRY(s->part_a.alloc(t.ntiles)); HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
   HIP_TRY(s->part_f.alloc(s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
   HIP_TRY(hipHostMalloc((void**)&s->h_scal, 2 * sizeof(KrylovScalars)));
@@ -635,19 +632,25 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
 
   Ctx& c = s->c;
-  c.nv = nv; c.nc = nc; c.ndof = ndof; c.nb = s->nb; c.nslices = t.nslices; c.n_work = (int)t.wl_slice.size();
-  c.nagg = t.nagg; c.ncoarse = s->ncoarse; c.n_vecwg = n_vecwg; c.ncp = nc; c.n_robin = 0;
+  c.nv = nv; c.nc = nc; c.ndof = ndof; c.nb = s->nb; c.nslices = t.nslices; c.ntiles = t.ntiles; c.n_work = (int)t.wl_slice.size();
+  c.nagg = t.nagg; c.ncoarse = s->ncoarse; c.tile_slots = t.tile_slots; c.n_robin = 0; c.use_coarse = 1;
   c.model = s->d_model.p; c.quad = s->d_quad.p; c.coords = s->coords.p; c.cells = s->cells.p;
   c.u = s->u.p; c.un = s->un.p; c.F = s->F.p; c.bcflag = s->bcflag.p; c.bcval = s->bcval.p;
   c.EF = s->EF.p; c.EJ = s->EJ.p; c.n2e_ptr = s->n2e_ptr.p; c.n2e = s->n2e.p;
   c.rowptr = s->rowptr.p; c.cols = s->cols.p; c.cptr = s->cptr.p; c.contrib = s->contrib.p;
-  c.vals = s->vals.p; c.slice_off = s->slice_off.p; c.slice_colbase = s->slice_colbase.p;
+  c.vals = s->vals.p; c.vals_s = s->vals_s.p; c.slice_off = s->slice_off.p; c.slice_colbase = s->slice_colbase.p;
+  c.slice_node0 = s->slice_node0.p; c.slice_nn = s->slice_nn.p; c.node_slice = s->node_slice.p;
   c.sell_cols = s->sell_cols.p; c.sell_aggslot = s->sell_aggslot.p; c.wl_slice = s->wl_slice.p; c.wl_kpos = s->wl_kpos.p;
-  c.sell_blk = s->sell_blk.p; c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
-  c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.AciT = s->AciT.p;
-  c.vw_node0 = s->vw_node0.p; c.vw_node1 = s->vw_node1.p; c.agg_vw_ptr = s->agg_vw_ptr.p; c.vw_agg = s->vw_agg.p; c.vw_slots = t.vw_slots;
-  c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp = s->kp.p; c.kv = s->kv.p; c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kq = s->kq.p;
-  c.pc_part = s->pc_part.p; c.yc = s->yc.p; c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
+  c.sell_blk = s->sell_blk.p; c.tile_slice0 = s->tile_slice0.p; c.tile_agg = s->tile_agg.p; c.tile_slot = s->tile_slot.p;
+  c.tile_aggs = s->tile_aggs.p; c.tile_nagg = s->tile_nagg.p;
+  c.tile_colptr = s->tile_colptr.p; c.tile_cols = s->tile_cols.p; c.tile_colslot = s->tile_colslot.p; c.sell_lcol = s->sell_lcol.p;
+  c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
+  c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.Aci = s->Aci.p;
+  c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp[0] = s->kp0.p; c.kp[1] = s->kp1.p; c.kv[0] = s->kv0.p; c.kv[1] = s->kv1.p;
+  c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.yc = s->yc.p;
+  c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
+  c.cpart_v[0] = s->cpart_v0.p; c.cpart_v[1] = s->cpart_v1.p; c.cpart_t = s->cpart_t.p;
+  c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;
@@ -767,7 +770,7 @@ int gmpnp_get_jacobian_csr(gmpnp_solver* s, int32_t* indptr, int32_t* indices, d
   int64_t pos = 0; indptr[0] = 0;
   std::vector<std::pair<int, int>> order;  // (file column node, kpos)
   for (int vf = 0; vf < t.nv; ++vf) {
-    const int I = t.iperm[vf], sl = I / t.S, il = I - sl * t.S;
+    const int I = t.iperm[vf], sl = t.node_slice[I], il = I - t.slice_node0[sl];
     order.clear();
     for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) order.push_back({t.perm[t.cols[k]], t.sellk[k]});
     std::sort(order.begin(), order.end());
@@ -788,10 +791,9 @@ int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y) {
   if (!s || !x || !y) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
   HIP_TRY(hipSetDevice(s->opts.device_id));
-  int rc = upload_vec(s, x, s->tmpx.p); if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(s->yc.p, 0, kMaxCoarse * sizeof(double), s->stream));
-  GMPNP_DISPATCH(s, rc = (launch_spmv<NF, 0>(s, s->tmpx.p, s->kt.p, false)));
-  if (rc) return rc;
+  int rc = upload_vec(s, x, s->kx.p); if (rc) return rc;
+  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
+                                       (const double*)s->kx.p, s->kt.p));
   HIP_TRY(hipGetLastError());
   return download_vec(s, s->kt.p, y);
 }
@@ -811,12 +813,12 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   if (mode == GMPNP_LINEAR_BLOCK_TRIDIAGONAL) {
     if (s->dim != 1) return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh");
     rc = tri_solve<7>(s, s->kr.p); if (rc) return rc;
-    rc = tri_apply<7>(s, s->tmpx.p, 0.0, 1.0); if (rc) return rc;
+    rc = tri_apply<7>(s, s->kx.p, 0.0, 1.0); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
     if (stats) { stats->iterations = 1; stats->converged = 1; stats->residual_norm = 0.0; stats->rhs_norm = bn; }
-    return download_vec(s, s->tmpx.p, x);
+    return download_vec(s, s->kx.p, x);
   }
   GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
   if (rc) return rc;
@@ -826,9 +828,9 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
   if (rc) return rc;
-  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->tmpx.p, 0.0, 1.0)));
+  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
   if (rc) return rc;
-  return download_vec(s, s->tmpx.p, x);
+  return download_vec(s, s->kx.p, x);
 }
 
 int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* z) {
@@ -847,9 +849,9 @@ int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* 
     if (*s->h_status & 6) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
   }
   rc = upload_vec(s, r, s->ky.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->tmpx.p, 0.0, 1.0)));
+  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
   if (rc) return rc;
-  return download_vec(s, s->tmpx.p, z);
+  return download_vec(s, s->kx.p, z);
 }
 
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {
@@ -859,18 +861,26 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
   HIP_TRY(hipSetDevice(s->opts.device_id));
   hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
   int rc = GMPNP_OK;
-  if (kernel == 0) HIP_TRY(hipMemsetAsync(s->yc.p, 0, kMaxCoarse * sizeof(double), s->stream));
   auto one = [&]() -> int {
     int r = GMPNP_OK;
     switch (kernel) {
-      case 0: GMPNP_DISPATCH(s, r = (launch_spmv<NF, 0>(s, s->kq.p, s->kt.p, false))); break;
+      case 0: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p)); break;
       case 1: GMPNP_DISPATCH(s, r = (launch_element<DIM, NF>(s, true))); break;
       case 2: GMPNP_DISPATCH(s, r = (launch_jac_gather<DIM, NF>(s))); break;
       case 3: GMPNP_DISPATCH(s, r = (launch_res_gather<DIM, NF>(s))); break;
+      case 4: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 5: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 6: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_a<NF>), dim3(grid_for(s->ncoarse, kCoarseThreads / 64)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
+      case 7: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_b<NF>), dim3(grid_for(s->ncoarse, kCoarseThreads / 64)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
+      case 8: hipLaunchKernelGGL(k_copy2, dim3(1), dim3(64), 0, s->stream, s->yc.p, (double*)nullptr, s->cpart_t.p, 64); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
     return r;
   };
+  if (kernel >= 4 && kernel <= 7) {  // Krylov kernels: a live (not finished) solve state
+    KrylovScalars z{}; z.rho[0] = z.rho[1] = 1.0; z.alpha = 1.0; z.omega = 1.0; z.beta = 0.5; z.tol = 0.0; z.max_iters = 1 << 30;
+    HIP_TRY(hipMemcpy(s->scal.p, &z, sizeof z, hipMemcpyHostToDevice));
+  }
   rc = one(); if (rc) return rc;  // warm
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipEventRecord(a, s->stream));
@@ -883,6 +893,33 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
   *avg_us = 1000.0 * ms / launches;
   if (kernel == 1 || kernel == 2) s->jacobian_valid = (kernel == 2) ? s->jacobian_valid : s->jacobian_valid;
   return GMPNP_OK;
+}
+
+// debug only (not declared in gmpnp.h): raw device buffers, internal order
+int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
+  const double* src = nullptr; int64_t cap = 0;
+  switch (which) {
+    case 0: src = s->krhat.p; cap = s->ndof; break;
+    case 1: src = s->vals_s.p; cap = (int64_t)s->vals_s.n; break;
+    case 2: src = s->Dinv.p; cap = (int64_t)s->Dinv.n; break;
+    case 3: src = s->Aci.p; cap = (int64_t)s->Aci.n; break;
+    case 4: src = s->vals.p; cap = (int64_t)s->vals.n; break;
+    case 5: src = s->Ac.p; cap = (int64_t)s->Ac.n; break;
+    case 6: src = s->kr.p; cap = s->ndof; break;
+    case 7: src = s->ky.p; cap = s->ndof; break;
+    case 8: src = s->ks.p; cap = s->ndof; break;
+    case 9: src = s->kt.p; cap = s->ndof; break;
+    case 10: src = s->kp0.p; cap = s->ndof; break;
+    case 11: src = s->kp1.p; cap = s->ndof; break;
+    case 12: src = s->kv0.p; cap = s->ndof; break;
+    case 13: src = s->kv1.p; cap = s->ndof; break;
+    case 14: src = s->yc.p; cap = 135; break;
+    default: return GMPNP_ERR_INVALID;
+  }
+  if (n > cap) n = cap;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
+  return (int)0;
 }
 
 int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched) {

@@ -16,26 +16,40 @@ constexpr int kVecBlock = 256;      // threads per workgroup of the vector kerne
 constexpr int kMaxRowAggs = 4;      // distinct coarse aggregates a block row may touch
 constexpr int kMaxCoarse = 140;     // coarse dimension limit: n^2 doubles must fit the 160 KiB LDS
 constexpr int kCoarseChunks = 32;   // node chunks per aggregate in the Galerkin-product reduction
+#ifndef GMPNP_SLICES_PER_TILE
+#define GMPNP_SLICES_PER_TILE 1
+#endif
+#ifndef GMPNP_KRYLOV_WAVES
+#define GMPNP_KRYLOV_WAVES 8
+#endif
+#ifndef GMPNP_ROW_PRELOAD
+#define GMPNP_ROW_PRELOAD 3
+#endif
+constexpr int kSlicesPerTile = GMPNP_SLICES_PER_TILE;    // SELL slices (of 7 or 9 block rows) per Krylov workgroup
+constexpr int kTileAggs = 6;         // coarse aggregates the rows of one tile may prolong from
+constexpr int kTileCols = 224;       // distinct column nodes a tile may reference (x staged in LDS: kTileCols*NF doubles)
 constexpr int kSlicePad = 16;       // per-(slice,kpos) column-index record length (>= rows per slice: 7 or 9)
 
-// Device scalars of one BiCGStab solve (one cache line; written by designated lanes, read after a kernel boundary).
+// Device scalars of one BiCGStab solve.  Each field has ONE writer kernel and is read only by later launches
+// (fields written by kernel A are read by B and vice versa; rho is double-buffered by iteration parity).
 struct KrylovScalars {
-  double rho;        // (rhat, r) of the iteration that just finished its update
-  double rho_next;   // (rhat, r) computed by vec1 for the iteration in flight
-  double alpha;
-  double tol;        // absolute threshold on ||r||_2
-  double rr;         // ||r||_2^2 seen by the last convergence test
-  int32_t iters;     // completed iterations
-  int32_t max_iters;
-  int32_t done;      // 1 = converged, 2 = max_iters, 3 = breakdown
-  int32_t it_cur;    // copy of iters made by vec1 (vec2 reads this one: it rewrites iters itself)
+  double rho[2];     // (rhat, r_k), slot k & 1, written by A(k)
+  double alpha;      // written by coarse_b(k)
+  double omega, beta; // written by coarse_a(k)
+  double tol;        // absolute threshold on ||r||_2 (host)
+  double rr;         // ||r||_2^2 seen by the last convergence test (B)
+  int32_t iters;     // completed iterations (B)
+  int32_t it_cur;    // iteration index of the A kernel in flight (A)
+  int32_t max_iters; // host
+  int32_t done;      // 1 = converged, 2 = max_iters, 3 = breakdown (published by B)
+  int32_t done_next; // verdict of coarse_b(k), turned into `done` by B(k)
+  int32_t pad_;
 };
 
 // Everything the kernels need, passed by value (kernarg segment).
 struct Ctx {
   // sizes
-  int32_t nv, nc, ndof, nb, nslices, n_work, nagg, ncoarse, n_vecwg, ncp;
-  int32_t n_robin;
+  int32_t nv, nc, ndof, nb, nslices, ntiles, n_work, nagg, ncoarse, tile_slots, n_robin, use_coarse;
   // model / quadrature (device copies)
   const gmpnp_model_t* model;
   const gmpnp_quadrature_t* quad;
@@ -67,15 +81,29 @@ struct Ctx {
   const int32_t* cols;     // [nb]
   const int32_t* cptr;     // [nb+1]
   const int32_t* contrib;  // e*16 + a*4 + b
-  // SELL-(rows per slice)-storage of the Jacobian: vals[slice_off[s] + (kpos*NF + j)*64 + lane], lane = Iloc*NF + i
-  double* vals;
+  // SELL storage of the Jacobian: vals[slice_off[s] + (kpos*NF + j)*64 + lane], lane = Iloc*NF + i, node = slice_node0[s] + Iloc
+  double* vals;     // A (assembled)
+  double* vals_s;   // As = A Dinv (k_scale_columns), same layout
   const int64_t* slice_off;     // [nslices+1] in doubles
   const int32_t* slice_colbase; // [nslices+1]
-  const int32_t* sell_cols;     // [(colbase+kpos)*kSlicePad + Iloc] column node | aggregate << 24 (padding: the row's own node)
+  const int32_t* slice_node0;   // [nslices] first node of the slice (slices are aggregate-aligned)
+  const int32_t* slice_nn;      // [nslices] nodes in the slice (<= S)
+  const int32_t* node_slice;    // [nv]
+  const int32_t* sell_cols;     // [(colbase+kpos)*kSlicePad + Iloc] column node | tile-local aggregate slot << 24 (padding: own node)
   const int32_t* sell_blk;      // same indexing: BSR block index, -1 = padding
   const uint8_t* sell_aggslot;  // same indexing: slot of the column's aggregate in row_aggs[I] (255 = padding)
   const int32_t* wl_slice;      // [n_work]
   const int32_t* wl_kpos;       // [n_work]
+  // tiles = row ranges of the Krylov workgroups (kSlicesPerTile slices of ONE aggregate)
+  const int32_t* tile_slice0;   // [ntiles+1]
+  const int32_t* tile_agg;      // [ntiles]
+  const int32_t* tile_slot;     // [ntiles] index of the tile inside its aggregate (partial-sum slot)
+  const int32_t* tile_aggs;     // [ntiles][kTileAggs] aggregates the tile prolongs from
+  const int32_t* tile_nagg;     // [ntiles]
+  const int32_t* tile_colptr;   // [ntiles+1] distinct column nodes of the tile's rows
+  const int32_t* tile_cols;     // global node ids (ascending)
+  const int32_t* tile_colslot;  // aggregate of each of them
+  const int32_t* sell_lcol;     // [(colbase+kpos)*kSlicePad + Iloc] index of the block's column in the tile's list
   // preconditioner
   double* Dinv;                 // [nv][NF][NF]
   const int32_t* agg;           // [nv]
@@ -84,27 +112,25 @@ struct Ctx {
   double* AP;                   // [ndof][kMaxRowAggs][NF]
   double* AcPart;               // [kCoarseChunks][ncoarse][ncoarse] partial sums of Ac
   double* Ac;                   // [ncoarse][ncoarse]
-  double* AciT;                 // transposed inverse
-  // vector-kernel workgroup table (aggregate- and node-aligned)
-  const int32_t* vw_node0;      // [n_vecwg]
-  const int32_t* vw_node1;
-  const int32_t* agg_vw_ptr;    // [nagg+1]
-  const int32_t* vw_agg;        // [n_vecwg] aggregate of each vector workgroup
-  int32_t vw_slots;             // partial-sum slots per coarse dof (>= workgroups per aggregate)
-  // Krylov vectors
-  double* kr;    // r
+  double* Aci;                  // inverse, row major
+  // Krylov vectors (right-scaled system A Dinv (I + P Aci P^T) y = b)
+  double* kr;
   double* krhat;
-  double* kp;
-  double* kv;
+  double* kp[2];   // ping-pong: p_k lives in kp[k & 1]
+  double* kv[2];
   double* ks;
   double* kt;
   double* ky;
-  double* kq;    // Dinv * (p or s)
-  double* pc_part;  // [ncoarse][vw_slots] restriction partials, slot = workgroup index inside its aggregate
-  double* yc;       // [ncoarse]
-  double* part_rr;  // [n_vecwg]
-  double* part_a;   // [nslices]      (rhat, v)
-  double* part_b;   // [4][nslices]   (t,s) (t,t) (rhat,s) (rhat,t)
+  double* kx;      // work vector (plain SpMV input / M^{-1} output)
+  double* yc;      // [ncoarse] coarse solve of the half-iteration in flight
+  // coarse level: per-tile partial restrictions written by the kernels' epilogues (double-buffered by iteration parity)
+  double* cpart_r[2];  // P^T r_k (kernel A)
+  double* cpart_p[2];  // P^T p_k (kernel A)
+  double* cpart_v[2];  // [ncoarse][tile_slots] partial restriction of v (kernel A, by iteration parity) / k_restrict output
+  double* cpart_t;  // [ncoarse][tile_slots] partial restriction of t (kernel B)
+  double* part_rr;  // [ntiles]      ||r||^2 partials (A)
+  double* part_a;   // [ntiles]      (rhat, v) (A)
+  double* part_b;   // [4][ntiles]   (t,s) (t,t) (rhat,s) (rhat,t) (B)
   double* part_f;   // residual-norm partials
   KrylovScalars* scal;
   int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse)
@@ -124,8 +150,10 @@ struct Topology {
   std::vector<uint8_t> sell_aggslot;
   int nagg = 0;
   std::vector<int32_t> agg, agg_start, row_aggs;
-  std::vector<int32_t> vw_node0, vw_node1, agg_vw_ptr, vw_agg;
-  int vw_slots = 0;
+  std::vector<int32_t> slice_node0, slice_nn, node_slice;            // aggregate-aligned slices
+  std::vector<int32_t> tile_slice0, tile_agg, tile_slot, agg_tile_ptr, tile_aggs, tile_nagg;
+  std::vector<int32_t> tile_colptr, tile_cols, tile_colslot, sell_lcol;
+  int ntiles = 0, tile_slots = 0;
 };
 
 // Builds every table above; returns an error message or "" on success.

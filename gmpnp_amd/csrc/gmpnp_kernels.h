@@ -4,9 +4,7 @@
 //   k_res_gather   race-free node gather of the residual, Dirichlet rows b = x - g, ||b||^2      (a5, a6)
 //   k_jac_gather   race-free gather of the node-block Jacobian straight into SELL storage,
 //                  identity Dirichlet rows                                                        (a5, a6)
-//   k_spmv         SELL block SpMV with the coarse prolongation folded into the x gather          (a7)
-//   k_vec1/k_vec2  fused BiCGStab vector updates + block-Jacobi apply + coarse restriction        (a7)
-//   k_coarse       coarse GEMV with the LDS-inverted Galerkin operator                            (a7)
+//   k_bicg_a/b     fused BiCGStab half-iterations: vector updates + coarse solve + SELL SpMV + dots (a7)
 //
 // Reference mathematics: 3D/MPNP_CO2ER_pore.py:505-769, 1D/MPNP_CO2ER_EDL.py:383-595.
 #pragma once
@@ -325,9 +323,8 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
   if (wave >= c.n_work) return;
   const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
   const int Iloc = lane / NF, i = lane - Iloc * NF;
-  if (Iloc >= S) return;
-  const int I = s * S + Iloc;
-  if (I >= c.nv) return;
+  if (Iloc >= c.slice_nn[s]) return;
+  const int I = c.slice_node0[s] + Iloc;
   const int k = c.sell_blk[(size_t)(c.slice_colbase[s] + kpos) * kSlicePad + Iloc];
   if (k < 0) return;  // padding stays zero (set at create)
   const int J = c.cols[k];
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(64) void k_block_inverse(const Ctx c) {
   __shared__ double A[NF * NF][64];
   const int I = blockIdx.x * 64 + threadIdx.x, t = threadIdx.x;
   if (I >= c.nv) return;
-  const int s = I / S, Iloc = I - s * S;
+  const int s = c.node_slice[I], Iloc = I - c.slice_node0[s];
   const double* base = c.vals + c.slice_off[s] + Iloc * NF;  // the diagonal block is SELL position 0
   for (int i = 0; i < NF; ++i)
     for (int j = 0; j < NF; ++j) A[i * NF + j][t] = base[(size_t)j * kWave + i];
@@ -445,16 +442,15 @@ __global__ __launch_bounds__(64) void k_coarse_rows(const Ctx c) {
   constexpr int S = kWave / NF;
   const int s = blockIdx.x, lane = threadIdx.x;
   const int Iloc = lane / NF, i = lane - Iloc * NF;
-  if (Iloc >= S) return;
-  const int I = s * S + Iloc;
-  if (I >= c.nv) return;
+  if (Iloc >= c.slice_nn[s]) return;
+  const int I = c.slice_node0[s] + Iloc;
   double acc[kMaxRowAggs][NF];
 #pragma unroll
   for (int q = 0; q < kMaxRowAggs; ++q)
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[q][j] = 0.0;
   const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
-  const double* base = c.vals + c.slice_off[s] + lane;
+  const double* base = c.vals_s + c.slice_off[s] + lane;  // the coarse operator is built from the column-scaled matrix
   for (int kp = 0; kp < mx; ++kp) {
     const int slot = c.sell_aggslot[(size_t)(cb + kp) * kSlicePad + Iloc];
     if (slot == 255) continue;
@@ -612,242 +608,594 @@ __global__ __launch_bounds__(512) void k_coarse_invert(const Ctx c) {
     __syncthreads();
   }
   if (sing) { if (t == 0) atomicOr(c.status, 4); return; }
-  for (int q = t; q < n * n; q += nt) c.AciT[q] = A[q];  // row-major inverse (name kept: see k_coarse)
+  for (int q = t; q < n * n; q += nt) c.Aci[q] = A[q];
 }
 
-// ---------------------------------------------------------------------------------------------
-// Coarse solve yc = Aci pc, one wave per coarse row (4 rows per workgroup).  pc = fixed-order sum of the
-// restriction partials pc_part[coarse dof][slot] (slots of absent workgroups stay zero).  The matrix row and
-// the partials are requested together, so the kernel is one memory round trip plus a wave reduction.
-// ---------------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(kVecBlock) void k_coarse(const Ctx c, int use_coarse) {
-  __shared__ double pc[kMaxCoarse];
-  if (c.scal->done) return;
-  const int n = c.ncoarse, t = threadIdx.x;
-  const int row = blockIdx.x * 4 + (t >> 6), lane = t & 63;
-  if (!use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
-  double a[3];
+// =================================================================================================
+// Fused BiCGStab.  System: A Dinv (I + P Aci P^T) y = b, x = Dinv (I + P Aci P^T) y, with
+//   As  = A Dinv          the column-scaled Jacobian (k_scale_columns, once per Newton iteration)
+//   Aci = (P^T As P)^-1   the inverse Galerkin operator on the slab aggregates.
+// One iteration is TWO launches.  Workgroup = one tile (kSlicesPerTile slices of one aggregate, 8 waves per slice).
+//   A(k): omega, beta from B(k-1)'s partials; own rows: y += alpha p + omega s, r = s - omega t, p = r + beta (p - omega v);
+//         the SpMV gathers p at the column nodes ON THE FLY from (s, t, p_old, v_old), adds the prolonged coarse
+//         correction and produces v = As (p + P Aci P^T p); epilogue: (rhat,v), ||r||^2, partial restriction of v.
+//   B(k): convergence test, alpha; own rows s = r - alpha v; SpMV gathers s from (r, v): t = As (s + P Aci P^T s);
+//         epilogue: (t,s) (t,t) (rhat,s) (rhat,t), partial restriction of t.
+// The restrictions P^T p and P^T s are never formed from the fine vectors: they follow the same recurrences on the
+// coarse level (P^T r, P^T p kept in crc/cpc; P^T v, P^T t come from the kernels' epilogue partials), so the coarse
+// solve needs no reduction of its own and every workgroup evaluates just the coarse rows its columns prolong from.
+// All reductions are fixed-order sums of per-tile partials: results are bitwise reproducible.
+// =================================================================================================
+constexpr int kKrylovWaves = GMPNP_KRYLOV_WAVES;                          // waves per slice
+constexpr int kKrylovThreads = kSlicesPerTile * kKrylovWaves * kWave;    // 512
+template <int NF> constexpr int stage_count() { return (kTileCols * NF + kKrylovThreads - 1) / kKrylovThreads; }
+
+constexpr int kCoarseThreads = 512;  // coarse kernels: one wave per coarse row, 8 rows per workgroup
+
+// ---- prologue pieces.  Each has a load() that only ISSUES global loads into registers (called first thing in the
+// kernel, so every request of the launch is in flight together) and a later reduce step on LDS.
+
+// K partial arrays of n entries each (part + q*stride) -> totals for every thread.
+template <int K>
+struct PartialSums {
+  static constexpr int U = 4;  // entries per thread held in registers: n <= U * kKrylovThreads, else a tail loop
+  double v[K];
+  __device__ inline void load(const double* __restrict__ part, int n, int stride) {
+    double r[K][U];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { const int cc = lane + 64 * k; a[k] = (row < n && cc < n) ? c.AciT[(size_t)row * n + cc] : 0.0; }
+    for (int u = 0; u < U; ++u) {
+      const int i = threadIdx.x + u * kCoarseThreads;
+#pragma unroll
+      for (int q = 0; q < K; ++q) r[q][u] = (i < n) ? part[(size_t)q * stride + i] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) sacc += r[q][u];
+      for (int i = threadIdx.x + U * kCoarseThreads; i < n; i += kCoarseThreads) sacc += part[(size_t)q * stride + i];
+      v[q] = sacc;
+    }
+  }
+  // lds: [ (kCoarseThreads/64) * K ]; one barrier inside
+  __device__ inline void reduce(double* lds, double (&out)[K]) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    if (lane == 0)
+#pragma unroll
+      for (int q = 0; q < K; ++q) lds[w * K + q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < kCoarseThreads / 64; ++ww) sacc += lds[ww * K + q];
+      out[q] = sacc;
+    }
+  }
+};
+
+// Restriction partials part[slot][n] -> per-thread chunk sums for coarse dof d = t % n, chunk = t / n (3 chunks).
+struct SlotSums {
+  static constexpr int CH = 3, U = 16;
+  double acc;
+  __device__ inline void load(const double* __restrict__ part, int n, int slots) {
+    const int t = threadIdx.x, d = t % n, ch = t / n;
+    double r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int slot = ch + CH * u;
+      r[u] = (ch < CH && slot < slots) ? part[(size_t)slot * n + d] : 0.0;
+    }
+    double sacc = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) sacc += r[u];
+    if (ch < CH)
+      for (int slot = ch + CH * U; slot < slots; slot += CH) sacc += part[(size_t)slot * n + d];
+    acc = sacc;
+  }
+  __device__ inline void to_lds(double* lds /* [CH][kMaxCoarse] */, int n) const {
+    const int t = threadIdx.x, d = t % n, ch = t / n;
+    if (ch < CH) lds[ch * kMaxCoarse + d] = acc;
+  }
+  static __device__ inline double total(const double* lds, int d) {
+    return (lds[d] + lds[kMaxCoarse + d]) + lds[2 * kMaxCoarse + d];
+  }
+};
+
+// Rows of Aci this tile needs (tile_nagg*NF <= kTileAggs*NF rows), 16 lanes per row, two row passes per thread.
+template <int NF>
+struct CoarseRows {
+  static constexpr int U = 9;  // ceil(kMaxCoarse / 16)
+  static constexpr int PASS = (kTileAggs * NF + kKrylovThreads / 16 - 1) / (kKrylovThreads / 16);
+  double a[PASS][U];
+  __device__ inline void load(const Ctx& c, int tile) {
+    const int n = c.ncoarse, t = threadIdx.x, nrows = c.tile_nagg[tile] * NF;
+#pragma unroll
+    for (int ps = 0; ps < PASS; ++ps) {
+      const int r = (t >> 4) + ps * (kKrylovThreads >> 4);
+      const bool on = r < nrows;
+      const int slot = on ? r / NF : 0, f = r - slot * NF;
+      const double* arow = c.Aci + (size_t)(c.tile_aggs[tile * kTileAggs + slot] * NF + (on ? f : 0)) * n;
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int cc = (t & 15) + 16 * u; a[ps][u] = (on && cc < n) ? arow[cc] : 0.0; }
+    }
+  }
+  __device__ inline void apply(const Ctx& c, int tile, const double* pcs, double* ycl) const {
+    const int n = c.ncoarse, t = threadIdx.x, nrows = c.tile_nagg[tile] * NF;
+#pragma unroll
+    for (int ps = 0; ps < PASS; ++ps) {
+      const int r = (t >> 4) + ps * (kKrylovThreads >> 4);
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int cc = (t & 15) + 16 * u; if (cc < n) acc += a[ps][u] * pcs[cc]; }
+      acc += __shfl_xor(acc, 1, 16); acc += __shfl_xor(acc, 2, 16); acc += __shfl_xor(acc, 4, 16); acc += __shfl_xor(acc, 8, 16);
+      if ((t & 15) == 0 && r < nrows) ycl[r] = acc;
+    }
+  }
+};
+
+// Matrix part shared by the tile kernels: the wave's first PRE blocks are requested up front, x comes from LDS.
+template <int NF>
+struct TileRows {
+  static constexpr int PRE = GMPNP_ROW_PRELOAD;
+  double av[PRE][NF];
+  int lc[PRE];
+  int s, Iloc, i, cb, mx, w;
+  bool slice_ok, active;
+  const double* base;
+
+  __device__ inline void load(const Ctx& c, const double* __restrict__ vals, int tile) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sl = wv / kKrylovWaves;
+    w = wv - sl * kKrylovWaves;
+    s = c.tile_slice0[tile] + sl;
+    slice_ok = s < c.tile_slice0[tile + 1];
+    Iloc = lane / NF; i = lane - Iloc * NF;
+    active = slice_ok && Iloc < c.slice_nn[s];
+    cb = 0; mx = 0; base = vals;
+    if (active) { cb = c.slice_colbase[s]; mx = c.slice_colbase[s + 1] - cb; base = vals + c.slice_off[s] + lane; }
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const int kp = w + u * kKrylovWaves;
+      const bool on = active && kp < mx;
+      lc[u] = on ? c.sell_lcol[(size_t)(cb + kp) * kSlicePad + Iloc] : 0;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) av[u][j] = on ? base[(size_t)(kp * NF + j) * kWave] : 0.0;
+    }
+  }
+
+  __device__ inline double dot(const Ctx& c, const double* xs) const {
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const double* xv = xs + lc[u] * NF;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc += av[u][j] * xv[j];
+    }
+    if (active) {
+      for (int kp = w + PRE * kKrylovWaves; kp < mx; kp += kKrylovWaves) {  // rows with more than PRE*8 blocks
+        const double* xv = xs + c.sell_lcol[(size_t)(cb + kp) * kSlicePad + Iloc] * NF;
+        const double* ap = base + (size_t)kp * NF * kWave;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc += ap[(size_t)j * kWave] * xv[j];
+      }
+    }
+    return acc;
+  }
+};
+
+constexpr int kStagePre = 2;  // staged x entries per thread requested up front (tiles with more columns: tail loop)
+
+// ---- coarse kernels: scalars of the half-iteration, coarse recurrences, yc = Aci * (P^T p  or  P^T s) ------------
+// Every workgroup redundantly reduces the per-tile partials (fixed order) and evaluates 8 rows of the coarse solve;
+// workgroup 0 publishes the scalars and the new coarse vectors for the following launches.
+template <int NF>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const int k) {
+  __shared__ double cs[4][SlotSums::CH * kMaxCoarse];
+  __shared__ double pcs[kMaxCoarse];
+  __shared__ double lred[(kCoarseThreads / 64) * 4];
+  KrylovScalars* sc = c.scal;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, n = c.ncoarse;
+  const int par = k & 1;  // the iteration index comes from the host: no load stands in front of the requests below
+  const bool first = (k == 0);
+  const int row = blockIdx.x * (kCoarseThreads / 64) + wv;
+  // all requests first (the `done` flag among them: a finished solve still issues them, then exits)
+  const int done_flag = sc->done;
+  double arow[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; arow[u] = (c.use_coarse && row < n && cc < n) ? c.Aci[(size_t)row * n + cc] : 0.0; }
+  PartialSums<4> psum;
+  // Exact restrictions of the ACTUAL fine vectors of iteration k-1 (epilogue partials of A(k-1) and B(k-1)): the
+  // coarse vectors are rebuilt from them every iteration, nothing accumulates on the coarse level.
+  SlotSums sv_, st_, sr_, sp_;
+  if (!first) psum.load(c.part_b, c.ntiles, c.ntiles);
+  if (c.use_coarse) {
+    sv_.load(c.cpart_v[par ^ 1], n, c.tile_slots);  // P^T v_{k-1} (k = 0: P^T b from k_restrict)
+    if (!first) {
+      st_.load(c.cpart_t, n, c.tile_slots);          // P^T t_{k-1}
+      sr_.load(c.cpart_r[par ^ 1], n, c.tile_slots);  // P^T r_{k-1}
+      sp_.load(c.cpart_p[par ^ 1], n, c.tile_slots);  // P^T p_{k-1}
+    }
+  }
+  double alpha = 0.0, rho_old = 1.0, rho_new = 0.0, omega = 0.0, beta = 0.0;
+  if (first) rho_new = sc->rho[1];  // the host puts (rhat, r_0) = ||b||^2 there
+  else { alpha = sc->alpha; rho_old = sc->rho[par ^ 1]; }
+  if (done_flag) return;
+  if (c.use_coarse) { sv_.to_lds(cs[0], n); if (!first) { st_.to_lds(cs[1], n); sr_.to_lds(cs[2], n); sp_.to_lds(cs[3], n); } }
+  if (!first) {
+    double tot[4];
+    psum.reduce(lred, tot);
+    omega = tot[0] / tot[1];
+    rho_new = tot[2] - omega * tot[3];
+    beta = (rho_new / rho_old) * (alpha / omega);
+  } else {
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && t == 0) { sc->omega = omega; sc->beta = beta; sc->rho[par] = rho_new; }
+  if (!c.use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
   if (t < n) {
-    const double* pp = c.pc_part + (size_t)t * c.vw_slots;
-    double s = 0.0;
-#pragma unroll 16
-    for (int k = 0; k < c.vw_slots; ++k) s += pp[k];
-    pc[t] = s;
+    const double vc = SlotSums::total(cs[0], t);
+    double rcn, pcn;
+    if (first) { rcn = vc; pcn = vc; }
+    else {
+      const double tc = SlotSums::total(cs[1], t), rc_old = SlotSums::total(cs[2], t), pc_old = SlotSums::total(cs[3], t);
+      rcn = (rc_old - alpha * vc) - omega * tc;       // P^T r_k
+      pcn = rcn + beta * (pc_old - omega * vc);       // P^T p_k
+    }
+    pcs[t] = pcn;
   }
   __syncthreads();
   if (row >= n) return;
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { const int cc = lane + 64 * k; if (cc < n) s += a[k] * pc[cc]; }
-  s = wave_sum(s);
-  if (lane == 0) c.yc[row] = s;
-}
-
-// ---------------------------------------------------------------------------------------------
-// SELL block SpMV: out = A (x + P yc).  One workgroup (NW waves) per slice, the waves split the block columns;
-// lane = (block row in slice, scalar row).  Every value load is a 504-byte contiguous wave read.
-// MODE 0: plain.  MODE 1: part_a = (rhat, out).  MODE 2: part_b = (out,s) (out,out) (rhat,s) (rhat,out).
-// ---------------------------------------------------------------------------------------------
-template <int NF, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void k_spmv(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
-  constexpr int S = kWave / NF;
-  __shared__ double red[NW][64];
-  if (MODE != 0 && c.scal->done) return;
-  const int s = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int Iloc = lane / NF, i = lane - Iloc * NF;
-  const int I = s * S + Iloc;
-  const bool active = (Iloc < S) && (I < c.nv);
-  const int cb = c.slice_colbase[s], mx = c.slice_colbase[s + 1] - cb;
-  const double* base = c.vals + c.slice_off[s] + lane;
-  double rh = 0.0, sv = 0.0;  // operands of the fused dot products: requested early
-  if (MODE != 0 && w == 0 && active) { rh = c.krhat[I * NF + i]; if (MODE == 2) sv = c.ks[I * NF + i]; }
   double acc = 0.0;
-  if (active) {
-#pragma unroll 2
-    for (int kp = w; kp < mx; kp += NW) {
-      const int pk = c.sell_cols[(size_t)(cb + kp) * kSlicePad + Iloc];
-      const double* xv = x + (size_t)(pk & 0xFFFFFF) * NF;
-      const double* yv = c.yc + (pk >> 24) * NF;
-      const double* av = base + (size_t)kp * NF * kWave;
 #pragma unroll
-      for (int j = 0; j < NF; ++j) acc += av[(size_t)j * kWave] * (xv[j] + yv[j]);
-    }
-  }
-  red[w][lane] = acc;
-  __syncthreads();
-  if (w != 0) return;
-  double tot = 0.0;
-#pragma unroll
-  for (int q = 0; q < NW; ++q) tot += red[q][lane];
-  const int r = I * NF + i;
-  if (active) out[r] = tot;
-  if (MODE == 1) {
-    const double d = wave_sum(active ? rh * tot : 0.0);
-    if (lane == 0) c.part_a[s] = d;
-  } else if (MODE == 2) {
-    const double tv = active ? tot : 0.0;
-    const double d0 = wave_sum(tv * sv), d1 = wave_sum(tv * tv), d2 = wave_sum(rh * sv), d3 = wave_sum(rh * tv);
-    if (lane == 0) {
-      c.part_b[s] = d0; c.part_b[c.nslices + s] = d1; c.part_b[2 * c.nslices + s] = d2; c.part_b[3 * c.nslices + s] = d3;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// BiCGStab vector kernels.  Workgroup = whole nodes of ONE aggregate (so the restriction partial is a
-// per-workgroup sum), thread = dof.  Right preconditioning: the Krylov space lives on y, x = M^{-1} y.
-//
-// k_vec1: (iteration > 0) omega = (t,s)/(t,t); y += alpha p + omega s; r = s - omega t;
-//         rho' = (rhat,s) - omega (rhat,t); beta = (rho'/rho)(alpha/omega); p = r + beta (p - omega v)
-//         (iteration 0)  p = r
-//         then q = Dinv p, restriction partial of p, partial of (r,r).
-// k_vec2: convergence test on (r,r); alpha = rho'/(rhat,v); s = r - alpha v; q = Dinv s; restriction of s.
-// ---------------------------------------------------------------------------------------------
-template <int NF>
-__device__ inline void dinv_restrict(const Ctx& c, int wg, int n0, int nnodes, int tid, bool valid, double val,
-                                     const double (&drow)[NF], double* lv /* [kVecBlock] */) {
-  lv[tid] = valid ? val : 0.0;
-  __syncthreads();
-  if (valid) {
-    const int nl = tid / NF;
-    double q = 0.0;
-#pragma unroll
-    for (int mI = 0; mI < NF; ++mI) q += drow[mI] * lv[nl * NF + mI];
-    c.kq[n0 * NF + tid] = q;
-  }
-  if (tid < NF) {
-    double s = 0.0;
-    for (int nl = 0; nl < nnodes; ++nl) s += lv[nl * NF + tid];
-    const int g = c.vw_agg[wg];
-    c.pc_part[(size_t)(g * NF + tid) * c.vw_slots + (wg - c.agg_vw_ptr[g])] = s;
-  }
+  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; if (cc < n) acc += arow[u] * pcs[cc]; }
+  acc = wave_sum(acc);
+  if (lane == 0) c.yc[row] = acc;
 }
 
 template <int NF>
-__device__ inline void load_dinv_row(const Ctx& c, int r, bool valid, double (&drow)[NF]) {
-#pragma unroll
-  for (int mI = 0; mI < NF; ++mI) drow[mI] = valid ? c.Dinv[(size_t)r * NF + mI] : 0.0;
-}
-
-template <int NF>
-__global__ __launch_bounds__(kVecBlock) void k_vec1(const Ctx c) {
-  __shared__ double lv[kVecBlock];
-  __shared__ double lred[16];
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) {
+  __shared__ double cs[2][SlotSums::CH * kMaxCoarse];
+  __shared__ double pcs[kMaxCoarse];
+  __shared__ double lred[(kCoarseThreads / 64) * 2];
   KrylovScalars* sc = c.scal;
-  if (sc->done) return;
-  const int wg = blockIdx.x, tid = threadIdx.x;
-  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
-  const bool valid = tid < nnodes * NF;
-  const int r = n0 * NF + tid;
-  const int iters = sc->iters;
-  const bool first = (iters == 0);
-  // every operand is requested before the partial sums are reduced (independent round trips overlap)
-  double drow[NF];
-  load_dinv_row<NF>(c, r, valid, drow);
-  double sv = 0.0, tv = 0.0, pold = 0.0, vv = 0.0, yv = 0.0, r0 = 0.0;
-  if (valid) {
-    if (first) r0 = c.kr[r];
-    else { sv = c.ks[r]; tv = c.kt[r]; pold = c.kp[r]; vv = c.kv[r]; yv = c.ky[r]; }
-  }
-  double pv = 0.0, rn = 0.0, rho_next;
-  if (first) {
-    rho_next = sc->rho;
-    rn = r0; pv = r0;
-  } else {
-    const double alpha = sc->alpha, rho = sc->rho;
-    double tot[4];
-    sum_partials<4>(c.part_b, c.nslices, c.nslices, tot, lred);
-    const double ts = tot[0], tt = tot[1], rs = tot[2], rt = tot[3];
-    const double omega = ts / tt;
-    rho_next = rs - omega * rt;
-    const double beta = (rho_next / rho) * (alpha / omega);
-    if (valid) {
-      c.ky[r] = yv + alpha * pold + omega * sv;
-      rn = sv - omega * tv;
-      c.kr[r] = rn;
-      pv = rn + beta * (pold - omega * vv);
-    }
-  }
-  if (valid) c.kp[r] = pv;
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, pv, drow, lv);
-  double v[1] = {rn * rn};
-  block_sum<1>(v, lred);
-  if (tid == 0) {
-    c.part_rr[wg] = v[0];
-    if (wg == 0) { sc->rho_next = rho_next; sc->it_cur = iters; }
-  }
-}
-
-template <int NF>
-__global__ __launch_bounds__(kVecBlock) void k_vec2(const Ctx c) {
-  __shared__ double lv[kVecBlock];
-  __shared__ double lred[16];
-  KrylovScalars* sc = c.scal;
-  if (sc->done) return;
-  const int wg = blockIdx.x, tid = threadIdx.x;
-  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
-  const bool valid = tid < nnodes * NF;
-  const int r = n0 * NF + tid;
-  // vec2 only reads scalars that vec1 (the previous launch) wrote and only writes scalars that vec1 reads
-  const double rho_next = sc->rho_next, tol = sc->tol;
-  const int iters = sc->it_cur, max_iters = sc->max_iters;
-  double drow[NF];
-  load_dinv_row<NF>(c, r, valid, drow);
-  const double rv_ = valid ? c.kr[r] : 0.0, vv = valid ? c.kv[r] : 0.0;
-  double rr[1], rv[1];
-  sum_partials<1>(c.part_rr, c.n_vecwg, c.n_vecwg, rr, lred);
-  sum_partials<1>(c.part_a, c.nslices, c.nslices, rv, lred);
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, n = c.ncoarse;
+  const int par = k & 1;
+  const int done_flag = sc->done, max_iters = sc->max_iters;
+  const double rho_new = sc->rho[par], tol = sc->tol;
+  const int row = blockIdx.x * (kCoarseThreads / 64) + wv;
+  double arow[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; arow[u] = (c.use_coarse && row < n && cc < n) ? c.Aci[(size_t)row * n + cc] : 0.0; }
+  PartialSums<2> psum;
+  { PartialSums<1> pa, pr;
+    pa.load(c.part_a, c.ntiles, c.ntiles);
+    pr.load(c.part_rr, c.ntiles, c.ntiles);
+    psum.v[0] = pa.v[0]; psum.v[1] = pr.v[0]; }
+  SlotSums sv_, sr_;
+  if (c.use_coarse) { sv_.load(c.cpart_v[par], n, c.tile_slots); sr_.load(c.cpart_r[par], n, c.tile_slots); }
+  if (done_flag) return;
+  if (c.use_coarse) { sv_.to_lds(cs[0], n); sr_.to_lds(cs[1], n); }
+  double tot[2];
+  psum.reduce(lred, tot);
+  const double rv = tot[0], rr = tot[1];
   int done = 0;
-  if (!(rr[0] == rr[0]) || !(rv[0] == rv[0])) done = 3;                  // NaN
-  else if (sqrt(rr[0]) <= tol) done = 1;
-  else if (iters >= max_iters) done = 2;
-  else if (rv[0] == 0.0 || rho_next == 0.0) done = 3;                    // breakdown
-  if (done) {
-    if (wg == 0 && tid == 0) { sc->rr = rr[0]; sc->done = done; }
+  if (!(rr == rr) || !(rv == rv)) done = 3;
+  else if (sqrt(rr) <= tol) done = 1;
+  else if (k >= max_iters) done = 2;
+  else if (rv == 0.0 || rho_new == 0.0) done = 3;
+  // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
+  const double alpha = done ? 0.0 : rho_new / rv;
+  if (blockIdx.x == 0 && t == 0) { sc->alpha = alpha; sc->rr = rr; sc->done_next = done; }
+  if (done) return;
+  if (!c.use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
+  if (t < n) pcs[t] = SlotSums::total(cs[1], t) - alpha * SlotSums::total(cs[0], t);  // P^T s = P^T r_k - alpha P^T v_k
+  __syncthreads();
+  if (row >= n) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; if (cc < n) acc += arow[u] * pcs[cc]; }
+  acc = wave_sum(acc);
+  if (lane == 0) c.yc[row] = acc;
+}
+
+// ---- fused half-iterations ------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) {
+  constexpr int NW = kKrylovWaves;
+  __shared__ double red[kSlicesPerTile * NW][64];
+  __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
+  __shared__ double dpart[kSlicesPerTile][2];
+  __shared__ double xs[kTileCols * NF];
+  KrylovScalars* sc = c.scal;
+  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int sl = wv / NW;
+  const int par = k & 1, n = c.ncoarse;
+  const bool first = (k == 0);
+  const int done_flag = sc->done;
+  const double alpha = sc->alpha, omega = sc->omega, beta = sc->beta;
+  const double* __restrict__ po = c.kp[par ^ 1];
+  const double* __restrict__ vo = c.kv[par ^ 1];
+  // every global request of this launch, issued together
+  TileRows<NF> rows;
+  rows.load(c, c.vals_s, tile);
+  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
+  double st_s[kStagePre], st_t[kStagePre], st_p[kStagePre], st_v[kStagePre], st_y[kStagePre];
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int q = t + u * kKrylovThreads;
+    st_s[u] = st_t[u] = st_p[u] = st_v[u] = st_y[u] = 0.0;
+    if (q < nst) {
+      const int cl = q / NF, f = q - cl * NF;
+      const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
+      st_y[u] = c.yc[c.tile_colslot[c0 + cl] * NF + f];
+      if (first) st_s[u] = c.kr[idx];
+      else { st_s[u] = c.ks[idx]; st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx]; }
+    }
+  }
+  double own_s = 0.0, own_t = 0.0, own_p = 0.0, own_v = 0.0, own_y = 0.0, own_rh = 0.0;
+  int own_r = 0;
+  if (rows.w == 0 && rows.active) {
+    own_r = (c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i;
+    own_rh = c.krhat[own_r];
+    if (first) own_s = c.kr[own_r];
+    else { own_s = c.ks[own_r]; own_t = c.kt[own_r]; own_p = po[own_r]; own_v = vo[own_r]; own_y = c.ky[own_r]; }
+  }
+  if (done_flag) return;
+  // stage x = p_new + P yc for the tile's column nodes
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int q = t + u * kKrylovThreads;
+    if (q < nst) {
+      const double pj = first ? st_s[u] : (st_s[u] - omega * st_t[u]) + beta * (st_p[u] - omega * st_v[u]);
+      xs[q] = pj + st_y[u];
+    }
+  }
+  for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
+    const int cl = q / NF, f = q - cl * NF;
+    const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
+    const double pj = first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
+    xs[q] = pj + c.yc[c.tile_colslot[c0 + cl] * NF + f];
+  }
+  __syncthreads();
+  red[wv][lane] = rows.dot(c, xs);
+  __syncthreads();
+  // own rows, dots, partial restriction
+  if (rows.w == 0) {
+    double tot = 0.0, rn = 0.0, pn = 0.0;
+    if (rows.active) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
+      if (first) { rn = own_s; pn = rn; }
+      else {
+        c.ky[own_r] = own_y + alpha * own_p + omega * own_s;
+        rn = own_s - omega * own_t;
+        c.kr[own_r] = rn;
+        pn = rn + beta * (own_p - omega * own_v);
+      }
+      c.kp[par][own_r] = pn;
+      c.kv[par][own_r] = tot;
+    }
+    outv[0][sl][lane] = tot; outv[1][sl][lane] = rn; outv[2][sl][lane] = pn;
+    const double d0 = wave_sum(own_rh * tot), d1 = wave_sum(rn * rn);
+    if (lane == 0) { dpart[sl][0] = d0; dpart[sl][1] = d1; }
+  }
+  __syncthreads();
+  if (t < 3 * NF) {  // partial restrictions of v, r, p over the tile's rows (all in aggregate tile_agg)
+    const int which = t / NF, f = t - which * NF;
+    double sacc = 0.0;
+    for (int q = 0; q < kSlicesPerTile; ++q)
+      for (int il = 0; il < kWave / NF; ++il) sacc += outv[which][q][il * NF + f];
+    double* dstp = which == 0 ? c.cpart_v[par] : (which == 1 ? c.cpart_r[par] : c.cpart_p[par]);
+    dstp[(size_t)c.tile_slot[tile] * n + c.tile_agg[tile] * NF + f] = sacc;
+  } else if (t == 64) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
+    c.part_a[tile] = a0; c.part_rr[tile] = a1;
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) {
+  constexpr int NW = kKrylovWaves;
+  __shared__ double red[kSlicesPerTile * NW][64];
+  __shared__ double outv[kSlicesPerTile][64];
+  __shared__ double dpart[kSlicesPerTile][4];
+  __shared__ double xs[kTileCols * NF];
+  KrylovScalars* sc = c.scal;
+  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int sl = wv / NW;
+  const int done_flag = sc->done, dn = sc->done_next;  // dn: verdict of k_coarse_b(k) on ||r_k||
+  const int par = k & 1, n = c.ncoarse;
+  const double alpha = sc->alpha;
+  const double* __restrict__ vn = c.kv[par];
+  TileRows<NF> rows;
+  rows.load(c, c.vals_s, tile);
+  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
+  double st_r[kStagePre], st_v[kStagePre], st_y[kStagePre];
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int q = t + u * kKrylovThreads;
+    st_r[u] = st_v[u] = st_y[u] = 0.0;
+    if (q < nst) {
+      const int cl = q / NF, f = q - cl * NF;
+      const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
+      st_y[u] = c.yc[c.tile_colslot[c0 + cl] * NF + f];
+      st_r[u] = c.kr[idx]; st_v[u] = vn[idx];
+    }
+  }
+  double own_r_ = 0.0, own_v = 0.0, own_rh = 0.0;
+  int own_r = 0;
+  if (rows.w == 0 && rows.active) {
+    own_r = (c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i;
+    own_r_ = c.kr[own_r]; own_v = vn[own_r]; own_rh = c.krhat[own_r];
+  }
+  if (done_flag) return;
+  if (dn) {
+    if (tile == 0 && t == 0) sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
     return;
   }
-  const double alpha = rho_next / rv[0];
-  double sv = 0.0;
-  if (valid) { sv = rv_ - alpha * vv; c.ks[r] = sv; }
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, sv, drow, lv);
-  if (wg == 0 && tid == 0) { sc->alpha = alpha; sc->rho = rho_next; sc->rr = rr[0]; sc->iters = iters + 1; }
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int q = t + u * kKrylovThreads;
+    if (q < nst) xs[q] = (st_r[u] - alpha * st_v[u]) + st_y[u];
+  }
+  for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
+    const int cl = q / NF, f = q - cl * NF;
+    const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
+    xs[q] = (c.kr[idx] - alpha * vn[idx]) + c.yc[c.tile_colslot[c0 + cl] * NF + f];
+  }
+  __syncthreads();
+  red[wv][lane] = rows.dot(c, xs);
+  __syncthreads();
+  if (rows.w == 0) {
+    double tt = 0.0, sv = 0.0;
+    if (rows.active) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) tt += red[sl * NW + q][lane];
+      sv = own_r_ - alpha * own_v;
+      c.ks[own_r] = sv;
+      c.kt[own_r] = tt;
+    }
+    outv[sl][lane] = tt;
+    const double d0 = wave_sum(tt * sv), d1 = wave_sum(tt * tt), d2 = wave_sum(own_rh * sv), d3 = wave_sum(own_rh * tt);
+    if (lane == 0) { dpart[sl][0] = d0; dpart[sl][1] = d1; dpart[sl][2] = d2; dpart[sl][3] = d3; }
+  }
+  __syncthreads();
+  if (t < NF) {
+    double sacc = 0.0;
+    for (int q = 0; q < kSlicesPerTile; ++q)
+      for (int il = 0; il < kWave / NF; ++il) sacc += outv[q][il * NF + t];
+    c.cpart_t[(size_t)c.tile_slot[tile] * n + c.tile_agg[tile] * NF + t] = sacc;
+  } else if (t == 64) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      double a0 = 0.0;
+      for (int q = 0; q < kSlicesPerTile; ++q) a0 += dpart[q][m];
+      c.part_b[(size_t)m * c.ntiles + tile] = a0;
+    }
+    if (tile == 0) sc->iters = k + 1;
+  }
 }
 
-// x = M^{-1} y = Dinv y + P Aci P^T y, in three steps: k_vec_final (q = Dinv y, restrict y), k_coarse, k_apply.
+// Plain y = A x with the UNSCALED matrix (parity hook, partitioned driver); same tiling as the Krylov kernels.
 template <int NF>
-__global__ __launch_bounds__(kVecBlock) void k_vec_final(const Ctx c) {
-  __shared__ double lv[kVecBlock];
-  const int wg = blockIdx.x, tid = threadIdx.x;
-  const int n0 = c.vw_node0[wg], nnodes = c.vw_node1[wg] - n0;
-  const bool valid = tid < nnodes * NF;
-  double drow[NF];
-  load_dinv_row<NF>(c, n0 * NF + tid, valid, drow);
-  dinv_restrict<NF>(c, wg, n0, nnodes, tid, valid, valid ? c.ky[n0 * NF + tid] : 0.0, drow, lv);
+__global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
+  constexpr int NW = kKrylovWaves;
+  __shared__ double red[kSlicesPerTile * NW][64];
+  __shared__ double xs[kTileCols * NF];
+  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int sl = wv / NW;
+  TileRows<NF> rows;
+  rows.load(c, c.vals, tile);
+  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
+  for (int q = t; q < nst; q += kKrylovThreads) {
+    const int cl = q / NF, f = q - cl * NF;
+    xs[q] = x[(size_t)c.tile_cols[c0 + cl] * NF + f];
+  }
+  __syncthreads();
+  red[wv][lane] = rows.dot(c, xs);
+  __syncthreads();
+  if (rows.w != 0 || !rows.active) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
+  out[(c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i] = tot;
 }
 
-// dst[r] = scale_dst * dst[r] + scale_x * (q[r] + yc[agg]);  Newton update: u -= omega dx  (scale_dst 1, scale_x -omega)
+// As = A Dinv: one wave per (slice, block position) scales the NF-entry row pieces of its block by Dinv of the column node.
 template <int NF>
-__global__ __launch_bounds__(kVecBlock) void k_apply(const Ctx c, double* __restrict__ dst, double scale_dst, double scale_x) {
-  const int r = blockIdx.x * kVecBlock + threadIdx.x;
-  if (r >= c.ndof) return;
-  const int I = r / NF, f = r - I * NF;
-  const double x = c.kq[r] + c.yc[c.agg[I] * NF + f];
-  dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * x;
+__global__ __launch_bounds__(kVecBlock) void k_scale_columns(const Ctx c) {
+  const int wave = (blockIdx.x * kVecBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= c.n_work) return;
+  const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
+  const int Iloc = lane / NF;
+  if (Iloc >= c.slice_nn[s]) return;
+  const size_t rec = (size_t)(c.slice_colbase[s] + kpos) * kSlicePad + Iloc;
+  const size_t off = c.slice_off[s] + (size_t)kpos * NF * kWave + lane;
+  if (c.sell_blk[rec] < 0) return;  // padding stays zero in vals_s as well
+  const double* d = c.Dinv + (size_t)(c.sell_cols[rec] & 0xFFFFFF) * NF * NF;
+  double a[NF], o[NF];
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI) a[mI] = c.vals[off + (size_t)mI * kWave];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) o[j] = 0.0;
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) o[j] += a[mI] * d[mI * NF + j];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) c.vals_s[off + (size_t)j * kWave] = o[j];
+}
+
+// Partial restriction of a fine vector per tile -> cpart_v (used for P^T b at the start and P^T y at the end).
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_restrict(const Ctx c, const double* __restrict__ x, double* __restrict__ part) {
+  __shared__ double lv[kSlicesPerTile * 64];
+  const int tile = blockIdx.x, t = threadIdx.x;
+  if (t < kSlicesPerTile * 64) {
+    const int sl = t >> 6, lane = t & 63, s = c.tile_slice0[tile] + sl;
+    const int Iloc = lane / NF, i = lane - Iloc * NF;
+    const bool active = s < c.tile_slice0[tile + 1] && Iloc < c.slice_nn[s];
+    lv[t] = active ? x[(c.slice_node0[s] + Iloc) * NF + i] : 0.0;
+  }
+  __syncthreads();
+  if (t < NF) {
+    double sacc = 0.0;
+    for (int q = 0; q < kSlicesPerTile; ++q)
+      for (int il = 0; il < kWave / NF; ++il) sacc += lv[q * 64 + il * NF + t];
+    part[(size_t)c.tile_slot[tile] * c.ncoarse + c.tile_agg[tile] * NF + t] = sacc;
+  }
+}
+
+// dst = scale_dst*dst + scale_x * Dinv (x + P Aci P^T x), P^T x taken from the partials k_restrict left in `part`.
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, const double* __restrict__ x, const double* __restrict__ part,
+                                                                double* __restrict__ dst, double scale_dst, double scale_x) {
+  __shared__ double pcs[kMaxCoarse];
+  __shared__ double ycl[kTileAggs * NF];
+  __shared__ double xv[kSlicesPerTile][64];
+  const int tile = blockIdx.x, t = threadIdx.x;
+  int own_slot = 0;
+  if (c.use_coarse) {
+    if (t < c.ncoarse) {
+      double sacc = 0.0;
+      for (int q = 0; q < c.tile_slots; ++q) sacc += part[(size_t)q * c.ncoarse + t];
+      pcs[t] = sacc;
+    }
+    __syncthreads();
+    CoarseRows<NF> crow;
+    crow.load(c, tile);
+    crow.apply(c, tile, pcs, ycl);
+    for (int z = 0; z < c.tile_nagg[tile]; ++z) if (c.tile_aggs[tile * kTileAggs + z] == c.tile_agg[tile]) own_slot = z;
+  } else if (t < kTileAggs * NF) {
+    ycl[t] = 0.0;
+  }
+  __syncthreads();
+  const int sl = t >> 6, lane = t & 63;
+  bool active = false; int I = 0, i = 0, Iloc = 0;
+  if (sl < kSlicesPerTile) {
+    const int s = c.tile_slice0[tile] + sl;
+    Iloc = lane / NF; i = lane - Iloc * NF;
+    active = s < c.tile_slice0[tile + 1] && Iloc < c.slice_nn[s];
+    if (active) { I = c.slice_node0[s] + Iloc; xv[sl][lane] = x[I * NF + i] + ycl[own_slot * NF + i]; }
+  }
+  __syncthreads();
+  if (!active) return;
+  const double* d = c.Dinv + ((size_t)I * NF + i) * NF;
+  double z = 0.0;
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI) z += d[mI] * xv[sl][Iloc * NF + mI];
+  const int r = I * NF + i;
+  dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * z;
 }
 
 __global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double v = src[i]; a[i] = v; if (b) b[i] = v; }
 }
-
-__global__ void k_fill(double* __restrict__ a, double v, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) a[i] = v;
-}
-
 
 // =================================================================================================
 // Direct solver for 1D meshes: block cyclic reduction of the block-tridiagonal Jacobian (NF x NF blocks).
@@ -988,7 +1336,7 @@ __global__ __launch_bounds__(kVecBlock) void k_tri_extract(const Ctx c, TriLevel
   const int idx = blockIdx.x * kVecBlock + threadIdx.x;
   if (idx >= c.nv * NF * NF) return;
   const int e = idx / c.nv, I = idx - e * c.nv, i = e / NF, j = e - i * NF;
-  const int s = I / S, il = I - s * S;
+  const int s = c.node_slice[I], il = I - c.slice_node0[s];
   const double* base = c.vals + c.slice_off[s] + il * NF + i;
   const int kl = tri_kpos[I * 3], kd = tri_kpos[I * 3 + 1], kr = tri_kpos[I * 3 + 2];
   l0.L[idx] = kl >= 0 ? base[(size_t)(kl * NF + j) * kWave] : 0.0;

@@ -9,7 +9,26 @@
 
 namespace gmpnp {
 
+static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t);
+
+// Two passes: the first (caller's order) fixes the aggregate count and the node degrees; nodes are then stably
+// re-sorted by decreasing degree INSIDE each aggregate (equal-length rows per SELL slice, aggregates stay the exact
+// slabs of the caller's order) and everything is rebuilt in that order.
 std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology& t) {
+  Topology first;
+  std::string err = build_pass(m, m.perm, nf, nagg_req, false, first);
+  if (!err.empty()) return err;
+  std::vector<int32_t> perm2(first.perm);
+  if (m.dim != 1)  // interval meshes keep the caller's path order (block-tridiagonal direct solver)
+  for (int g = 0; g < first.nagg; ++g)
+    std::stable_sort(perm2.begin() + first.agg_start[g], perm2.begin() + first.agg_start[g + 1], [&](int a, int b) {
+      const int ia = first.iperm[a], ib = first.iperm[b];
+      return (first.rowptr[ia + 1] - first.rowptr[ia]) > (first.rowptr[ib + 1] - first.rowptr[ib]);
+    });
+  return build_pass(m, perm2.data(), nf, first.nagg, true, t);
+}
+
+static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t) {
   if (m.dim != 1 && m.dim != 3) return "mesh.dim must be 1 or 3";
   if (m.n_vertices <= 0 || m.n_cells <= 0 || !m.coords || !m.cells) return "empty mesh";
   t.dim = m.dim; t.nf = nf; t.nn = m.dim + 1; t.nv = m.n_vertices; t.nc = m.n_cells;
@@ -19,7 +38,7 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   // ---- internal order -----------------------------------------------------------------------
   t.perm.resize(nv); t.iperm.assign(nv, -1);
   for (int i = 0; i < nv; ++i) {
-    int f = m.perm ? m.perm[i] : i;
+    int f = perm_in ? perm_in[i] : i;
     if (f < 0 || f >= nv || t.iperm[f] != -1) return "perm is not a permutation";
     t.perm[i] = f; t.iperm[f] = i;
   }
@@ -86,6 +105,7 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   while (nagg_max > 1 && (size_t)((nagg_max * nf) * (nagg_max * nf) + nagg_max * nf * nf + 2 * nf * nf) * sizeof(double) > 160u * 1024u) --nagg_max;
   int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : nagg_max;
   nagg = std::max(1, std::min(nagg, nv / 8 > 0 ? nv / 8 : 1));
+  if (fixed_nagg) nagg = nagg_req;
   for (;; --nagg) {  // shrink until no row touches more than kMaxRowAggs aggregates
     t.nagg = nagg; t.agg.resize(nv); t.agg_start.assign(nagg + 1, 0);
     for (int g = 0; g <= nagg; ++g) t.agg_start[g] = (int32_t)((int64_t)nv * g / nagg);
@@ -102,6 +122,7 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
       }
     }
     if (ok || nagg == 1) break;
+    if (fixed_nagg) return "internal error: aggregate count changed between passes";
   }
   nagg = t.nagg;
 
@@ -121,15 +142,53 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
       });
       for (size_t q = 0; q < ord.size(); ++q) t.sellk[ord[q]] = (int32_t)q;
     } }
+  // Slices are aggregate-aligned: the nodes of aggregate g are cut into slices of S nodes (the last one may be
+  // partial), consecutive kSlicesPerTile slices of one aggregate form a TILE = the row range of one Krylov workgroup,
+  // so the coarse restriction of a tile's rows is one partial sum into one aggregate.
   const int S = t.S;
-  t.nslices = (nv + S - 1) / S;
+  t.slice_node0.clear(); t.slice_nn.clear(); t.node_slice.assign(nv, 0);
+  t.tile_slice0.clear(); t.tile_agg.clear(); t.tile_slot.clear(); t.agg_tile_ptr.assign(nagg + 1, 0);
+  for (int g = 0; g < nagg; ++g) {
+    int slot = 0;
+    for (int n0 = t.agg_start[g]; n0 < t.agg_start[g + 1]; n0 += S) {
+      const int sidx = (int)t.slice_node0.size();
+      if ((sidx - (t.tile_slice0.empty() ? 0 : t.tile_slice0.back())) >= kSlicesPerTile || t.tile_agg.empty() ||
+          t.tile_agg.back() != g) {
+        t.tile_slice0.push_back(sidx); t.tile_agg.push_back(g); t.tile_slot.push_back(slot++);
+      }
+      const int nn_ = std::min(S, t.agg_start[g + 1] - n0);
+      t.slice_node0.push_back(n0); t.slice_nn.push_back(nn_);
+      for (int q = 0; q < nn_; ++q) t.node_slice[n0 + q] = sidx;
+    }
+    t.agg_tile_ptr[g + 1] = (int32_t)t.tile_slice0.size();
+    t.tile_slots = std::max(t.tile_slots, slot);
+  }
+  t.nslices = (int)t.slice_node0.size();
+  t.ntiles = (int)t.tile_slice0.size();
+  t.tile_slice0.push_back(t.nslices);
+  t.tile_slots = ((t.tile_slots + 7) / 8) * 8;
   t.slice_off.assign(t.nslices + 1, 0); t.slice_colbase.assign(t.nslices + 1, 0);
   for (int s = 0; s < t.nslices; ++s) {
     int mx = 0;
-    for (int I = s * S; I < std::min(nv, (s + 1) * S); ++I) mx = std::max(mx, t.rowptr[I + 1] - t.rowptr[I]);
+    for (int I = t.slice_node0[s]; I < t.slice_node0[s] + t.slice_nn[s]; ++I) mx = std::max(mx, t.rowptr[I + 1] - t.rowptr[I]);
     t.slice_colbase[s + 1] = t.slice_colbase[s] + mx;
     t.slice_off[s + 1] = t.slice_off[s] + (int64_t)mx * nf * kWave;
   }
+  // aggregates each tile prolongs from (its rows' column nodes): the fused Krylov kernels evaluate only these coarse rows
+  t.tile_aggs.assign((size_t)t.ntiles * kTileAggs, 0); t.tile_nagg.assign(t.ntiles, 0);
+  for (int tl = 0; tl < t.ntiles; ++tl)
+    for (int s = t.tile_slice0[tl]; s < t.tile_slice0[tl + 1]; ++s)
+      for (int I = t.slice_node0[s]; I < t.slice_node0[s] + t.slice_nn[s]; ++I)
+        for (int q = 0; q < kMaxRowAggs; ++q) {
+          const int g = t.row_aggs[(size_t)I * kMaxRowAggs + q];
+          if (g < 0) continue;
+          bool seen = false;
+          for (int z = 0; z < t.tile_nagg[tl]; ++z) seen |= (t.tile_aggs[(size_t)tl * kTileAggs + z] == g);
+          if (!seen) {
+            if (t.tile_nagg[tl] == kTileAggs) return "a Krylov tile touches more than kTileAggs coarse aggregates";
+            t.tile_aggs[(size_t)tl * kTileAggs + t.tile_nagg[tl]++] = g;
+          }
+        }
   // gather work list, heaviest SELL positions (diagonal blocks) first
   { int mxall = 0;
     for (int s = 0; s < t.nslices; ++s) mxall = std::max(mxall, t.slice_colbase[s + 1] - t.slice_colbase[s]);
@@ -139,32 +198,57 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   const int ncolrec = t.slice_colbase[t.nslices];
   t.sell_cols.assign((size_t)ncolrec * kSlicePad, 0); t.sell_aggslot.assign((size_t)ncolrec * kSlicePad, 255);
   t.sell_blk.assign((size_t)ncolrec * kSlicePad, -1);
+  std::vector<int> tile_of_slice(t.nslices);
+  for (int tl = 0; tl < t.ntiles; ++tl)
+    for (int s = t.tile_slice0[tl]; s < t.tile_slice0[tl + 1]; ++s) tile_of_slice[s] = tl;
+  // distinct column nodes per tile (the Krylov kernels stage x for exactly these in LDS) and the tile-local index of
+  // every block's column
+  t.tile_colptr.assign(t.ntiles + 1, 0); t.tile_cols.clear(); t.tile_colslot.clear();
+  t.sell_lcol.assign((size_t)ncolrec * kSlicePad, 0);
+  { std::vector<int> where(nv, -1), touched;
+    for (int tl = 0; tl < t.ntiles; ++tl) {
+      touched.clear();
+      for (int s = t.tile_slice0[tl]; s < t.tile_slice0[tl + 1]; ++s)
+        for (int I = t.slice_node0[s]; I < t.slice_node0[s] + t.slice_nn[s]; ++I)
+          for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) {
+            const int J = t.cols[k];
+            if (where[J] < 0) { where[J] = 0; touched.push_back(J); }
+          }
+      std::sort(touched.begin(), touched.end());
+      if (touched.size() > (size_t)kTileCols) return "a Krylov tile references more than kTileCols column nodes";
+      for (size_t q = 0; q < touched.size(); ++q) {
+        where[touched[q]] = (int)q;
+        t.tile_cols.push_back(touched[q]);
+        t.tile_colslot.push_back(t.agg[touched[q]]);
+      }
+      for (int s = t.tile_slice0[tl]; s < t.tile_slice0[tl + 1]; ++s)
+        for (int I = t.slice_node0[s]; I < t.slice_node0[s] + t.slice_nn[s]; ++I) {
+          const int il = I - t.slice_node0[s], mx = t.slice_colbase[s + 1] - t.slice_colbase[s];
+          for (int kp = 0; kp < mx; ++kp) t.sell_lcol[((size_t)t.slice_colbase[s] + kp) * kSlicePad + il] = where[I];  // padding
+          for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k)
+            t.sell_lcol[((size_t)t.slice_colbase[s] + t.sellk[k]) * kSlicePad + il] = where[t.cols[k]];
+        }
+      for (int J : touched) where[J] = -1;
+      t.tile_colptr[tl + 1] = (int32_t)t.tile_cols.size();
+    } }
   for (int I = 0; I < nv; ++I) {
-    const int s = I / S, il = I - s * S;
+    const int s = t.node_slice[I], il = I - t.slice_node0[s], tl = tile_of_slice[s];
     const int mx = t.slice_colbase[s + 1] - t.slice_colbase[s];
+    auto slot_of = [&](int g) {
+      for (int z = 0; z < t.tile_nagg[tl]; ++z) if (t.tile_aggs[(size_t)tl * kTileAggs + z] == g) return z;
+      return 0;
+    };
     for (int kp = 0; kp < mx; ++kp)  // padding: value stays zero, the index stays valid
-      t.sell_cols[((size_t)t.slice_colbase[s] + kp) * kSlicePad + il] = I | (t.agg[I] << 24);
+      t.sell_cols[((size_t)t.slice_colbase[s] + kp) * kSlicePad + il] = I | (slot_of(t.agg[I]) << 24);
     for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) {
       const size_t rec = ((size_t)t.slice_colbase[s] + t.sellk[k]) * kSlicePad + il;
       const int J = t.cols[k];
-      t.sell_cols[rec] = J | (t.agg[J] << 24);
+      t.sell_cols[rec] = J | (slot_of(t.agg[J]) << 24);
       t.sell_blk[rec] = k;
       for (int q = 0; q < kMaxRowAggs; ++q)
         if (t.row_aggs[(size_t)I * kMaxRowAggs + q] == t.agg[J]) t.sell_aggslot[rec] = (uint8_t)q;
     }
   }
-
-  // ---- vector-kernel workgroups: whole nodes, one aggregate each --------------------------------
-  const int npw = kVecBlock / nf;
-  t.agg_vw_ptr.assign(nagg + 1, 0);
-  for (int g = 0; g < nagg; ++g) {
-    for (int n0 = t.agg_start[g]; n0 < t.agg_start[g + 1]; n0 += npw) {
-      t.vw_node0.push_back(n0); t.vw_node1.push_back(std::min(n0 + npw, t.agg_start[g + 1])); t.vw_agg.push_back(g);
-    }
-    t.agg_vw_ptr[g + 1] = (int32_t)t.vw_node0.size();
-    t.vw_slots = std::max(t.vw_slots, t.agg_vw_ptr[g + 1] - t.agg_vw_ptr[g]);
-  }
-  t.vw_slots = ((t.vw_slots + 15) / 16) * 16;
   return "";
 }
 

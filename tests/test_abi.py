@@ -91,7 +91,7 @@ def test_newton_options_translation(backend):
 
 def test_slab_permutation(backend, pore10):
     _, mesh, _, _ = pore10
-    perm = backend.slab_permutation(mesh.coords, mesh.cells)
+    perm = backend.slab_permutation(mesh.coords, mesh.cells, window=224)
     assert sorted(perm) == list(range(mesh.num_vertices))
     z = mesh.coords[perm, 2]
     w = 224
