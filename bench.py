@@ -16,9 +16,11 @@ N > 1 (this round): one independent L_50_R_5 problem per GPU (the parameter-swee
 exchange is not wired into this bench yet (multi-GPU).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = SELL block SpMV (2 launches per BiCGStab iteration).  achieved = algorithmic bytes
-                of one SpMV (648 nb + 4 nb + 4 (nv+1) + 16 nd) / mean launch duration, sampled LIVE with
-                HIP events on the solver's own stream during the timed region (every 8th launch).
+  roofline      dominant kernels = the two fused BiCGStab half-iterations k_bicg_a / k_bicg_b (one SELL block SpMV each plus
+                the vector updates).  achieved = algorithmic bytes of ONE SpMV (648 nb + 4 nb + 4 (nv+1) +
+                16 nd; the vector traffic fused in is not counted) / mean kernel duration, sampled LIVE during the timed
+                region: every 8th launch carries a start/stop HIP event pair attached to the dispatch itself
+                (hipExtLaunchKernelGGL on the solver's stream), i.e. the kernel's own begin-to-end time.
   cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU, one thread) timed on rank 0 / N = 1 for ONE Newton
                 iteration of the same workload (about 20-30 s); kind = "port" (FEniCS itself cannot be installed).
 """
@@ -137,7 +139,7 @@ def main():
         nb, nd = dev.n_blocks, dev.ndof
         nf = dev.nf
         alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
-        mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(0, 200)
+        mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(4, 200)
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")
@@ -156,7 +158,8 @@ def main():
                        "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,
                        "krylov_iterations": kry,
                        "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv (SELL node-block SpMV, fp64)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV "
+                                                   "+ vector updates, fp64)", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"]},

@@ -27,7 +27,7 @@ EXPORTS = [
     "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
-    "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply",
+    "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
 ]
 
 
@@ -109,6 +109,7 @@ def load_library(path: str = None):
     lib.gmpnp_precond_apply.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
     lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
+    lib.gmpnp_event_overhead.argtypes = [c_void_p, c_int32, POINTER(c_double)]
     if path is None:
         _lib = lib
     return lib
@@ -342,6 +343,11 @@ class DeviceSolver:
     def time_kernel(self, kernel: int, launches: int = 50) -> float:
         us = c_double()
         self._check(self.lib.gmpnp_time_kernel(self._h, kernel, launches, byref(us)))
+        return us.value
+
+    def event_overhead(self, pairs: int = 200) -> float:
+        us = c_double()
+        self._check(self.lib.gmpnp_event_overhead(self._h, pairs, byref(us)))
         return us.value
 
     def spmv_profile(self):

@@ -46,6 +46,17 @@ struct KrylovScalars {
   int32_t pad_;
 };
 
+// Everything a Krylov workgroup needs to know about its tile (= one SELL slice), fetched with ONE load.
+struct TileRec {
+  int64_t slice_off;  // first value of the slice in vals / vals_s
+  int32_t colbase;    // first (slice, kpos) record of sell_lcol
+  int32_t mx;         // block positions in the slice
+  int32_t node0, nn;  // rows
+  int32_t ncols;      // distinct column nodes (listed at tile_cols + tile * col_stride)
+  int32_t agg, slot;  // aggregate of the rows, partial-sum slot inside it
+  int32_t pad_;
+};
+
 // Everything the kernels need, passed by value (kernarg segment).
 struct Ctx {
   // sizes
@@ -100,9 +111,10 @@ struct Ctx {
   const int32_t* tile_slot;     // [ntiles] index of the tile inside its aggregate (partial-sum slot)
   const int32_t* tile_aggs;     // [ntiles][kTileAggs] aggregates the tile prolongs from
   const int32_t* tile_nagg;     // [ntiles]
-  const int32_t* tile_colptr;   // [ntiles+1] distinct column nodes of the tile's rows
-  const int32_t* tile_cols;     // global node ids (ascending)
-  const int32_t* tile_colslot;  // aggregate of each of them
+  const TileRec* tile_rec;      // [ntiles]
+  int32_t col_stride;           // fixed stride of the per-tile column lists below
+  const int32_t* tile_cols;     // [ntiles][col_stride] distinct column nodes of the tile's rows (ascending; padding: node 0)
+  const int32_t* tile_colslot;  // [ntiles][col_stride] aggregate of each of them
   const int32_t* sell_lcol;     // [(colbase+kpos)*kSlicePad + Iloc] index of the block's column in the tile's list
   // preconditioner
   double* Dinv;                 // [nv][NF][NF]
@@ -152,7 +164,9 @@ struct Topology {
   std::vector<int32_t> agg, agg_start, row_aggs;
   std::vector<int32_t> slice_node0, slice_nn, node_slice;            // aggregate-aligned slices
   std::vector<int32_t> tile_slice0, tile_agg, tile_slot, agg_tile_ptr, tile_aggs, tile_nagg;
-  std::vector<int32_t> tile_colptr, tile_cols, tile_colslot, sell_lcol;
+  std::vector<int32_t> tile_colptr, tile_cols, tile_colslot, sell_lcol;  // tile_cols/tile_colslot: fixed stride col_stride
+  std::vector<TileRec> tile_rec;
+  int col_stride = 0;
   int ntiles = 0, tile_slots = 0;
 };
 

@@ -742,20 +742,18 @@ struct TileRows {
   static constexpr int PRE = GMPNP_ROW_PRELOAD;
   double av[PRE][NF];
   int lc[PRE];
-  int s, Iloc, i, cb, mx, w;
+  int s, Iloc, i, cb, mx, w, row;
   bool slice_ok, active;
   const double* base;
 
-  __device__ inline void load(const Ctx& c, const double* __restrict__ vals, int tile) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sl = wv / kKrylovWaves;
-    w = wv - sl * kKrylovWaves;
-    s = c.tile_slice0[tile] + sl;
-    slice_ok = s < c.tile_slice0[tile + 1];
+  __device__ inline void load(const Ctx& c, const double* __restrict__ vals, const TileRec& rec) {
+    const int lane = threadIdx.x & 63;
+    w = threadIdx.x >> 6;
+    s = 0; slice_ok = true;
     Iloc = lane / NF; i = lane - Iloc * NF;
-    active = slice_ok && Iloc < c.slice_nn[s];
-    cb = 0; mx = 0; base = vals;
-    if (active) { cb = c.slice_colbase[s]; mx = c.slice_colbase[s + 1] - cb; base = vals + c.slice_off[s] + lane; }
+    active = Iloc < rec.nn;
+    row = (rec.node0 + Iloc) * NF + i;
+    cb = rec.colbase; mx = active ? rec.mx : 0; base = vals + rec.slice_off + lane;
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
       const int kp = w + u * kKrylovWaves;
@@ -919,18 +917,29 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   const double* __restrict__ po = c.kp[par ^ 1];
   const double* __restrict__ vo = c.kv[par ^ 1];
   // every global request of this launch, issued together
+  // two independent chains: the tile record -> matrix values / local column indices, and the tile's column list
+  // (fixed stride: addressable without the record) -> operands of the staged x entries
+  const TileRec rec = c.tile_rec[tile];
+  const int c0 = tile * c.col_stride;
+  int st_col[kStagePre], st_agg[kStagePre];
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int cl = (t + u * kKrylovThreads) / NF;
+    const bool on = cl < c.col_stride;
+    st_col[u] = on ? c.tile_cols[c0 + cl] : 0; st_agg[u] = on ? c.tile_colslot[c0 + cl] : 0;
+  }
   TileRows<NF> rows;
-  rows.load(c, c.vals_s, tile);
-  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
+  rows.load(c, c.vals_s, rec);
+  const int nst = rec.ncols * NF;
   double st_s[kStagePre], st_t[kStagePre], st_p[kStagePre], st_v[kStagePre], st_y[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     st_s[u] = st_t[u] = st_p[u] = st_v[u] = st_y[u] = 0.0;
-    if (q < nst) {
+    if (q < c.col_stride * NF) {  // padding entries of the list point at node 0: harmless loads
       const int cl = q / NF, f = q - cl * NF;
-      const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-      st_y[u] = c.yc[c.tile_colslot[c0 + cl] * NF + f];
+      const size_t idx = (size_t)st_col[u] * NF + f;
+      st_y[u] = c.yc[st_agg[u] * NF + f];
       if (first) st_s[u] = c.kr[idx];
       else { st_s[u] = c.ks[idx]; st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx]; }
     }
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   double own_s = 0.0, own_t = 0.0, own_p = 0.0, own_v = 0.0, own_y = 0.0, own_rh = 0.0;
   int own_r = 0;
   if (rows.w == 0 && rows.active) {
-    own_r = (c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i;
+    own_r = rows.row;
     own_rh = c.krhat[own_r];
     if (first) own_s = c.kr[own_r];
     else { own_s = c.ks[own_r]; own_t = c.kt[own_r]; own_p = po[own_r]; own_v = vo[own_r]; own_y = c.ky[own_r]; }
@@ -989,7 +998,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[which][q][il * NF + f];
     double* dstp = which == 0 ? c.cpart_v[par] : (which == 1 ? c.cpart_r[par] : c.cpart_p[par]);
-    dstp[(size_t)c.tile_slot[tile] * n + c.tile_agg[tile] * NF + f] = sacc;
+    dstp[(size_t)rec.slot * n + rec.agg * NF + f] = sacc;
   } else if (t == 64) {
     double a0 = 0.0, a1 = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
@@ -1011,25 +1020,34 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
   const int par = k & 1, n = c.ncoarse;
   const double alpha = sc->alpha;
   const double* __restrict__ vn = c.kv[par];
+  const TileRec rec = c.tile_rec[tile];
+  const int c0 = tile * c.col_stride;
+  int st_col[kStagePre], st_agg[kStagePre];
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int cl = (t + u * kKrylovThreads) / NF;
+    const bool on = cl < c.col_stride;
+    st_col[u] = on ? c.tile_cols[c0 + cl] : 0; st_agg[u] = on ? c.tile_colslot[c0 + cl] : 0;
+  }
   TileRows<NF> rows;
-  rows.load(c, c.vals_s, tile);
-  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
+  rows.load(c, c.vals_s, rec);
+  const int nst = rec.ncols * NF;
   double st_r[kStagePre], st_v[kStagePre], st_y[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     st_r[u] = st_v[u] = st_y[u] = 0.0;
-    if (q < nst) {
+    if (q < c.col_stride * NF) {
       const int cl = q / NF, f = q - cl * NF;
-      const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-      st_y[u] = c.yc[c.tile_colslot[c0 + cl] * NF + f];
+      const size_t idx = (size_t)st_col[u] * NF + f;
+      st_y[u] = c.yc[st_agg[u] * NF + f];
       st_r[u] = c.kr[idx]; st_v[u] = vn[idx];
     }
   }
   double own_r_ = 0.0, own_v = 0.0, own_rh = 0.0;
   int own_r = 0;
   if (rows.w == 0 && rows.active) {
-    own_r = (c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i;
+    own_r = rows.row;
     own_r_ = c.kr[own_r]; own_v = vn[own_r]; own_rh = c.krhat[own_r];
   }
   if (done_flag) return;
@@ -1068,7 +1086,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
     double sacc = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[q][il * NF + t];
-    c.cpart_t[(size_t)c.tile_slot[tile] * n + c.tile_agg[tile] * NF + t] = sacc;
+    c.cpart_t[(size_t)rec.slot * n + rec.agg * NF + t] = sacc;
   } else if (t == 64) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1088,13 +1106,14 @@ __global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, cons
   __shared__ double xs[kTileCols * NF];
   const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int sl = wv / NW;
-  TileRows<NF> rows;
-  rows.load(c, c.vals, tile);
-  const int c0 = c.tile_colptr[tile], nst = (c.tile_colptr[tile + 1] - c0) * NF;
-  for (int q = t; q < nst; q += kKrylovThreads) {
+  const TileRec rec = c.tile_rec[tile];
+  const int c0 = tile * c.col_stride;
+  for (int q = t; q < c.col_stride * NF; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     xs[q] = x[(size_t)c.tile_cols[c0 + cl] * NF + f];
   }
+  TileRows<NF> rows;
+  rows.load(c, c.vals, rec);
   __syncthreads();
   red[wv][lane] = rows.dot(c, xs);
   __syncthreads();
@@ -1102,7 +1121,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, cons
   double tot = 0.0;
 #pragma unroll
   for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
-  out[(c.slice_node0[rows.s] + rows.Iloc) * NF + rows.i] = tot;
+  out[rows.row] = tot;
 }
 
 // As = A Dinv: one wave per (slice, block position) scales the NF-entry row pieces of its block by Dinv of the column node.
@@ -1190,6 +1209,14 @@ __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, cons
   for (int mI = 0; mI < NF; ++mI) z += d[mI] * xv[sl][Iloc * NF + mI];
   const int r = I * NF + i;
   dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * z;
+}
+
+// bandwidth probe: stream n doubles (16 B per lane) and keep one checksum per workgroup
+__global__ __launch_bounds__(256) void k_stream_read(const double2* __restrict__ a, size_t n2, double* __restrict__ out) {
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) { const double2 v = a[i]; acc += v.x + v.y; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc == 123.456) out[blockIdx.x] = acc;
 }
 
 __global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {

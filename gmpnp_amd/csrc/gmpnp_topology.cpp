@@ -231,6 +231,21 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
       for (int J : touched) where[J] = -1;
       t.tile_colptr[tl + 1] = (int32_t)t.tile_cols.size();
     } }
+  { static_assert(kSlicesPerTile == 1, "tile records describe one slice");
+    int mxc = 0;
+    for (int tl = 0; tl < t.ntiles; ++tl) mxc = std::max(mxc, t.tile_colptr[tl + 1] - t.tile_colptr[tl]);
+    t.col_stride = ((mxc + 15) / 16) * 16;
+    std::vector<int32_t> fc((size_t)t.ntiles * t.col_stride, 0), fs((size_t)t.ntiles * t.col_stride, 0);
+    t.tile_rec.resize(t.ntiles);
+    for (int tl = 0; tl < t.ntiles; ++tl) {
+      const int c0 = t.tile_colptr[tl], nc_ = t.tile_colptr[tl + 1] - c0, s0 = t.tile_slice0[tl];
+      for (int q = 0; q < nc_; ++q) { fc[(size_t)tl * t.col_stride + q] = t.tile_cols[c0 + q]; fs[(size_t)tl * t.col_stride + q] = t.tile_colslot[c0 + q]; }
+      TileRec r{};
+      r.slice_off = t.slice_off[s0]; r.colbase = t.slice_colbase[s0]; r.mx = t.slice_colbase[s0 + 1] - t.slice_colbase[s0];
+      r.node0 = t.slice_node0[s0]; r.nn = t.slice_nn[s0]; r.ncols = nc_; r.agg = t.tile_agg[tl]; r.slot = t.tile_slot[tl];
+      t.tile_rec[tl] = r;
+    }
+    t.tile_cols.swap(fc); t.tile_colslot.swap(fs); }
   for (int I = 0; I < nv; ++I) {
     const int s = t.node_slice[I], il = I - t.slice_node0[s], tl = tile_of_slice[s];
     const int mx = t.slice_colbase[s + 1] - t.slice_colbase[s];

@@ -136,7 +136,7 @@ typedef struct {
 typedef struct {
   int32_t device_id;      /* HIP device ordinal */
   int32_t n_aggregates;   /* coarse-space slabs; 0 = default (largest allowed by the LDS-resident coarse inverse) */
-  int32_t use_graph;      /* 0 = default (on): replay Krylov iterations from a captured hipGraph; 2 = off */
+  int32_t use_graph;      /* reserved (the Krylov launches carry the iteration index as an argument: eager only) */
   int32_t krylov_batch;   /* iterations launched between convergence read-backs; 0 = default */
   int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */
 } gmpnp_options_t;
@@ -193,10 +193,15 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t line
 int gmpnp_precond_apply(gmpnp_solver* s, int32_t linear_solver, const double* r, double* z);
 
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
- * events; kernel: 0 = Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather. */
+ * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
+ * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming
+ * read of the matrix buffer with 2048 / 512 / 8192 workgroups (bandwidth probes). */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
-/* SpMV launches sampled with HIP events since the last call (opts.profile_every): count, mean microseconds. */
+/* Fused BiCGStab half-iteration launches (k_bicg_a / k_bicg_b: SpMV + vector updates) sampled with HIP events since
+ * the last call (opts.profile_every): count, mean microseconds between the two events of a bracket. */
 int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched);
+/* Mean elapsed time of an EMPTY event pair on the handle's stream (what a sampled launch's bracket adds). */
+int gmpnp_event_overhead(gmpnp_solver* s, int32_t pairs, double* mean_us);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,6 @@ dev = backend.DeviceSolver(prob)
 dev.set_state(u, u)
 F, _ = dev.assemble(True)
 dev.linear_solve(F)  # builds the preconditioner, leaves Krylov vectors populated
-names = {0: "spmv_plain", 4: "bicg_a", 5: "bicg_b", 6: "coarse_a", 7: "coarse_b", 8: "tiny copy (1 wave)", 1: "element", 2: "jac_gather", 3: "res_gather"}
+names = {9: "stream 32MB (2048 wg)", 10: "stream 32MB (512 wg)", 11: "stream 32MB (8192 wg)", 0: "spmv_plain", 4: "bicg_a", 5: "bicg_b", 6: "coarse_a", 7: "coarse_b", 8: "tiny copy (1 wave)", 1: "element", 2: "jac_gather", 3: "res_gather"}
 for k, n in names.items():
     print("%-20s %.2f us (back-to-back)" % (n, dev.time_kernel(k, 200)))
