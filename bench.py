@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mesh", type=str, default="L_50_R_5", help="L_<nm>_R_<nm> pore mesh (default: the north-star mesh)")
+    p.add_argument("--refine", type=int, default=0, help="uniform refinements of the mesh (0 = the reference mesh itself)")
     return p.parse_args()
 
 
@@ -95,7 +96,7 @@ def main():
     from gmpnp_amd.problem import pore_dirichlet
 
     _, Lnm, _, Rnm = a.mesh.split("_")
-    run = PoreRun(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9,
+    run = PoreRun(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine,
                   device_kwargs={"device_id": local, "use_graph": False, "profile_every": 8})
     nv = run.mesh.num_vertices
 
@@ -143,7 +144,7 @@ def main():
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")
-        if os.path.exists(pmc) and a.mesh == "L_50_R_5":
+        if os.path.exists(pmc) and a.mesh == "L_50_R_5" and a.refine == 0:
             with open(pmc) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         out = {
@@ -152,7 +153,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "reference inputs shipped in data/utilities (%s mesh, parameters_pore.yaml, bulk_soln_0.5KHCO3.yaml); "
                     "deterministic, no RNG" % a.mesh,
-            "config": {"workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
+            "config": {"refine": a.refine, "n_vertices": nv,
+                       "workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
                                    "(Newton rtol=atol=1e-4, omega=0.9, max 50; linear solve = two-level BiCGStab to "
                                    "1e-10 relative residual)" % (a.mesh, a.steps - 1),
                        "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,

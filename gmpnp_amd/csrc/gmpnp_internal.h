@@ -23,7 +23,7 @@ constexpr int kCoarseChunks = 32;   // node chunks per aggregate in the Galerkin
 #define GMPNP_KRYLOV_WAVES 8
 #endif
 #ifndef GMPNP_ROW_PRELOAD
-#define GMPNP_ROW_PRELOAD 3
+#define GMPNP_ROW_PRELOAD 1
 #endif
 constexpr int kSlicesPerTile = GMPNP_SLICES_PER_TILE;    // SELL slices (of 7 or 9 block rows) per Krylov workgroup
 constexpr int kTileAggs = 6;         // coarse aggregates the rows of one tile may prolong from

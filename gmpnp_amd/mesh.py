@@ -246,3 +246,72 @@ def rcm_permutation(mesh: Mesh) -> np.ndarray:
     rowptr, cols = node_graph(mesh)
     g = csr_matrix((np.ones(cols.size, dtype=np.int8), cols, rowptr), shape=(mesh.num_vertices,) * 2)
     return np.asarray(reverse_cuthill_mckee(g, symmetric_mode=True), dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Uniform (red) refinement — SURVEY §8f item 1: the reference's mesh generator was never published and its larger
+# meshes are missing; refinement also gives problem sizes at which the kernels leave the cache-resident regime.
+# ---------------------------------------------------------------------------------------------
+def refine_uniform(mesh: Mesh):
+    """Split every tetrahedron into 8 (4 corner cells + the inner octahedron cut along the m02-m13 diagonal) or every
+    interval into 2.  Returns (fine mesh, edges (ne,2), edge_of) where the midpoint of edge k is vertex nv + k and
+    ``edge_of[(a, b)]`` lookups are provided through the returned ``midpoint(a, b)`` function."""
+    nv = mesh.num_vertices
+    c = mesh.cells
+    if mesh.dim == 1:
+        mid = 0.5 * (mesh.coords[c[:, 0]] + mesh.coords[c[:, 1]])
+        coords = np.concatenate([mesh.coords, mid])
+        m = nv + np.arange(len(c), dtype=np.int32)
+        cells = np.concatenate([np.stack([c[:, 0], m], 1), np.stack([m, c[:, 1]], 1)]).astype(np.int32)
+        return Mesh(dim=1, coords=coords, cells=cells), None
+    pairs = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
+    e = np.sort(c[:, pairs].reshape(-1, 2), axis=1).astype(np.int64)
+    key = e[:, 0] * nv + e[:, 1]
+    ukey, inv = np.unique(key, return_inverse=True)
+    edges = np.stack([ukey // nv, ukey % nv], 1).astype(np.int32)
+    coords = np.concatenate([mesh.coords, 0.5 * (mesh.coords[edges[:, 0]] + mesh.coords[edges[:, 1]])])
+    m = (nv + inv.reshape(-1, 6)).astype(np.int32)  # m01 m02 m03 m12 m13 m23
+    v0, v1, v2, v3 = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+    m01, m02, m03, m12, m13, m23 = (m[:, k] for k in range(6))
+    kids = [(v0, m01, m02, m03), (v1, m01, m12, m13), (v2, m02, m12, m23), (v3, m03, m13, m23),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    cells = np.concatenate([np.stack(k, 1) for k in kids]).astype(np.int32)
+
+    def midpoint(a, b):
+        a, b = np.minimum(a, b).astype(np.int64), np.maximum(a, b).astype(np.int64)
+        return (nv + np.searchsorted(ukey, a * nv + b)).astype(np.int32)
+
+    return Mesh(dim=3, coords=coords, cells=cells), midpoint
+
+
+def refine_pore(mesh: Mesh, bnd: PoreBoundaries):
+    """Refine a marked pore mesh once; child facets inherit their parent's marker (the geometric marking rule of the
+    reference, an absolute tolerance on r^2, would swallow interior facets on finer meshes: SURVEY Q5)."""
+    fine, midpoint = refine_uniform(mesh)
+    ds_facets, dirichlet_vertices, counts = {}, {}, {}
+    for value in (1, 2, 3):
+        sel = bnd.markers == value
+        out = []
+        for fv in (bnd.fv[sel & bnd.exterior], bnd.fv[sel & ~bnd.exterior]):
+            if len(fv) == 0:
+                out.append(np.zeros((0, 3), dtype=np.int32))
+                continue
+            a, b, c = fv[:, 0], fv[:, 1], fv[:, 2]
+            mab, mac, mbc = midpoint(a, b), midpoint(a, c), midpoint(b, c)
+            out.append(np.concatenate([np.stack(k, 1) for k in ((a, mab, mac), (b, mab, mbc), (c, mac, mbc), (mab, mbc, mac))]).astype(np.int32))
+        ds_facets[value] = out[0]
+        dirichlet_vertices[value] = np.unique(np.concatenate([out[0].ravel(), out[1].ravel()])).astype(np.int32)
+        counts[value] = (len(out[0]), len(out[1]))
+    # marker table of the fine mesh (exterior facets of the fine mesh that descend from marked parents)
+    ffv, fext, _ = fine.facets()
+    markers = np.full(len(ffv), _UNMARKED, dtype=np.int64)
+    nvf = fine.num_vertices
+    fkey = (ffv[:, 0].astype(np.int64) * nvf + ffv[:, 1]) * nvf + ffv[:, 2]
+    for value in (1, 3, 2):
+        kids = np.sort(ds_facets[value], axis=1).astype(np.int64)
+        k = (kids[:, 0] * nvf + kids[:, 1]) * nvf + kids[:, 2]
+        pos = np.searchsorted(fkey, k)
+        ok = (pos < len(fkey)) & (fkey[np.minimum(pos, len(fkey) - 1)] == k)
+        markers[pos[ok]] = value
+    return fine, PoreBoundaries(markers=markers, fv=ffv, exterior=fext, dirichlet_vertices=dirichlet_vertices,
+                                ds_facets=ds_facets, counts=counts)

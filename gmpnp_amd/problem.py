@@ -78,9 +78,14 @@ def pore_dirichlet(pp, bnd, co2_value=None):
     return merge_dirichlet(bcs, ns + 1)
 
 
-def pore_problem(pp, mesh: Mesh, quad: Quadrature = None):
-    """Problem + boundary record for the 3D pore (reference 3D:329-382,460-467)."""
+def pore_problem(pp, mesh: Mesh, quad: Quadrature = None, refine: int = 0):
+    """Problem + boundary record for the 3D pore (reference 3D:329-382,460-467).  ``refine`` > 0 applies that many
+    uniform refinements with inherited markers (gmpnp_amd.mesh.refine_pore); returns (problem, boundaries) of the
+    mesh actually used (``problem.coords/cells``)."""
     bnd = mark_pore_boundaries(mesh, pp.aspect_pore, pore_wall_tolerance(pp.L, pp.R))
+    for _ in range(refine):
+        from .mesh import refine_pore
+        mesh, bnd = refine_pore(mesh, bnd)
     dofs, vals = pore_dirichlet(pp, bnd)
     prob = Problem(coords=mesh.coords, cells=mesh.cells, model=pp.model, quad=quad,
                    wall_facets=bnd.ds_facets[2], exit_facets=bnd.ds_facets[3], bc_dofs=dofs, bc_vals=vals)

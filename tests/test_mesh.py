@@ -92,3 +92,25 @@ def test_positive_orientation_not_required():
     assert abs(m.cell_volumes()[0] - 1 / 6) < 1e-15
     fv, ext, _ = m.facets()
     assert len(fv) == 4 and ext.all()
+
+
+def test_uniform_refinement_conserves_geometry_and_markers():
+    from gmpnp_amd.mesh import refine_pore, refine_uniform
+    mesh = read_dolfin_xml(resolve_mesh_path(UTIL, "L_10_R_5.xml"))
+    bnd = mark_pore_boundaries(mesh, 0.5, 5e-3)
+    fine, fb = refine_pore(mesh, bnd)
+    assert fine.num_cells == 8 * mesh.num_cells
+    fv, ext, _ = mesh.facets()
+    nedges = len(np.unique(np.sort(mesh.cells[:, [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]].reshape(-1, 2), axis=1), axis=0))
+    assert fine.num_vertices == mesh.num_vertices + nedges
+    assert abs(fine.cell_volumes().sum() - mesh.cell_volumes().sum()) < 1e-13
+    assert fine.cell_volumes().min() > 0.1 * mesh.cell_volumes().min() / 8
+    for k in (1, 2, 3):
+        assert fb.counts[k][0] == 4 * bnd.counts[k][0]
+        assert abs(fine.facet_areas(fb.ds_facets[k]).sum() - mesh.facet_areas(bnd.ds_facets[k]).sum()) < 1e-12
+    ffv, fext, _ = fine.facets()
+    assert fext.sum() == 4 * ext.sum()  # the boundary is refined consistently: no hanging nodes
+    assert (fb.markers[fext] != 9999).all() and (fb.markers[~fext] == 9999).all()
+    m1 = read_dolfin_xml(resolve_mesh_path(UTIL, "1D_variable_1um_mesh_1090.xml.gz"))
+    f1, _ = refine_uniform(m1)
+    assert f1.num_cells == 2 * m1.num_cells and abs(f1.cell_volumes().sum() - 1.0) < 1e-13
