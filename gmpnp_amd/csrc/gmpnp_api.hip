@@ -35,11 +35,11 @@ struct DevBuf {
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t count, bool zero = true) {
+  hipError_t alloc(size_t count, bool zero = true, size_t pad = 0) {  // pad: zeroed elements behind the n counted ones
     if (p) { (void)hipFree(p); p = nullptr; }
     n = count;
-    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess && zero) e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count + pad, 1) * sizeof(T));
+    if (e == hipSuccess && (zero || pad)) e = hipMemset(p, 0, std::max<size_t>(count + pad, 1) * sizeof(T));
     return e;
   }
   hipError_t upload(const std::vector<T>& v) {
@@ -70,7 +70,7 @@ struct gmpnp_solver {
   DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
   DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, vals_s, Dinv, AP, AcPart, Ac, Aci;
   DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
-      part_rr, part_a, part_b, part_f;
+      part_a, part_b, part_f;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
       slice_node0, slice_nn, node_slice, sell_cols, sell_blk, wl_slice, wl_kpos, tile_slice0, tile_agg, tile_slot,
       tile_aggs, tile_nagg, tile_cols, tile_colslot, sell_lcol, agg, agg_start, row_aggs, status;
@@ -264,7 +264,7 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
     }
     ev = &s->ev_pool[s->ev_used++];
   }
-  const dim3 cg(grid_for(s->ncoarse, kCoarseThreads / 64));
+  const dim3 cg(std::max(1, s->t.nagg));
   // sampled launches attach the events to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the kernel's
   // own begin-to-end time, the quantity rocprofv3's kernel trace reports
   if (WHICH == 0) {
@@ -610,7 +610,8 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->n2e_ptr.upload(t.n2e_ptr)); HIP_TRY(s->n2e.upload(t.n2e));
   HIP_TRY(s->rowptr.upload(t.rowptr)); HIP_TRY(s->cols.upload(t.cols));
   HIP_TRY(s->cptr.upload(t.cptr)); HIP_TRY(s->contrib.upload(t.contrib));
-  HIP_TRY(s->vals.alloc((size_t)t.slice_off[t.nslices])); HIP_TRY(s->vals_s.alloc((size_t)t.slice_off[t.nslices]));
+  { const size_t pad = (size_t)kRowPad * nf * kWave;  // the Krylov kernels preload unconditionally past short slices
+    HIP_TRY(s->vals.alloc((size_t)t.slice_off[t.nslices], true, pad)); HIP_TRY(s->vals_s.alloc((size_t)t.slice_off[t.nslices], true, pad)); }
   HIP_TRY(s->slice_off.upload(t.slice_off)); HIP_TRY(s->slice_colbase.upload(t.slice_colbase));
   HIP_TRY(s->slice_node0.upload(t.slice_node0)); HIP_TRY(s->slice_nn.upload(t.slice_nn)); HIP_TRY(s->node_slice.upload(t.node_slice));
   HIP_TRY(s->sell_cols.upload(t.sell_cols)); HIP_TRY(s->sell_aggslot.upload(t.sell_aggslot));
@@ -626,10 +627,11 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx}) HIP_TRY(b->alloc(ndof));
-  HIP_TRY(s->yc.alloc(kMaxCoarse));
+  HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
-  HIP_TRY(s->part_rr.alloc(t.ntiles)); HIP_TRY(s->part_a.alloc(t.ntiles)); HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
+  HIP_TRY(s->part_a.alloc((size_t)2 * t.ntiles));  // (rhat,v) partials, then ||r||^2 partials
+  HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
   HIP_TRY(s->part_f.alloc(s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
   HIP_TRY(hipHostMalloc((void**)&s->h_scal, 2 * sizeof(KrylovScalars)));
@@ -658,7 +660,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.yc = s->yc.p;
   c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
   c.cpart_v[0] = s->cpart_v0.p; c.cpart_v[1] = s->cpart_v1.p; c.cpart_t = s->cpart_t.p;
-  c.part_rr = s->part_rr.p; c.part_a = s->part_a.p; c.part_b = s->part_b.p;
+  c.part_a = s->part_a.p; c.part_rr = s->part_a.p + t.ntiles; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;
@@ -878,8 +880,8 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
       case 3: GMPNP_DISPATCH(s, r = (launch_res_gather<DIM, NF>(s))); break;
       case 4: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
       case 5: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
-      case 6: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_a<NF>), dim3(grid_for(s->ncoarse, kCoarseThreads / 64)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
-      case 7: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_b<NF>), dim3(grid_for(s->ncoarse, kCoarseThreads / 64)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
+      case 6: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_a<NF>), dim3(std::max(1, s->t.nagg)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
+      case 7: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_b<NF>), dim3(std::max(1, s->t.nagg)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
       case 8: hipLaunchKernelGGL(k_copy2, dim3(1), dim3(64), 0, s->stream, s->yc.p, (double*)nullptr, s->cpart_t.p, 64); break;
       case 9: hipLaunchKernelGGL(k_stream_read, dim3(2048), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 10: hipLaunchKernelGGL(k_stream_read, dim3(512), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
@@ -924,6 +926,15 @@ int gmpnp_event_overhead(gmpnp_solver* s, int32_t pairs, double* mean_us) {
   return GMPNP_OK;
 }
 
+// debug only (not declared in gmpnp.h): resident workgroups per CU of the fused 3D Krylov kernels
+int gmpnp_debug_occupancy(int* out4) {
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_bicg_a<9>, kKrylovThreads, 0));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_bicg_b<9>, kKrylovThreads, 0));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[2], k_spmv_plain<9>, kKrylovThreads, 0));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[3], k_coarse_a<9>, kCoarseThreads, 0));
+  return GMPNP_OK;
+}
+
 // debug only (not declared in gmpnp.h): raw device buffers, internal order
 int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
   const double* src = nullptr; int64_t cap = 0;
@@ -942,7 +953,7 @@ int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
     case 11: src = s->kp1.p; cap = s->ndof; break;
     case 12: src = s->kv0.p; cap = s->ndof; break;
     case 13: src = s->kv1.p; cap = s->ndof; break;
-    case 14: src = s->yc.p; cap = 135; break;
+    case 14: src = s->yc.p; cap = (int64_t)s->yc.n; break;
     default: return GMPNP_ERR_INVALID;
   }
   if (n > cap) n = cap;

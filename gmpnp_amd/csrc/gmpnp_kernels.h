@@ -634,32 +634,45 @@ constexpr int kCoarseThreads = 512;  // coarse kernels: one wave per coarse row,
 
 // ---- prologue pieces.  Each has a load() that only ISSUES global loads into registers (called first thing in the
 // kernel, so every request of the launch is in flight together) and a later reduce step on LDS.
+// Every load is UNCONDITIONAL on a clamped (always valid) index and masked afterwards: a predicated load becomes a
+// branch, the compiler sinks the first use into it and waits there, and the prologue degenerates into one memory
+// round trip per load.
 
 // K partial arrays of n entries each (part + q*stride) -> totals for every thread.
 template <int K>
 struct PartialSums {
-  static constexpr int U = 4;  // entries per thread held in registers: n <= U * kKrylovThreads, else a tail loop
-  double v[K];
-  __device__ inline void load(const double* __restrict__ part, int n, int stride) {
-    double r[K][U];
+  static constexpr int U = 2;  // entries per thread requested up front: n <= U * kCoarseThreads, else the tail loop
+  double r[K][U];
+  __device__ inline void load(const double* __restrict__ part, int n, int stride) {  // straight-line: requests only
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = threadIdx.x + u * kCoarseThreads;
+      const int ic = min((int)threadIdx.x + u * kCoarseThreads, n - 1);
 #pragma unroll
-      for (int q = 0; q < K; ++q) r[q][u] = (i < n) ? part[(size_t)q * stride + i] : 0.0;
+      for (int q = 0; q < K; ++q) r[q][u] = part[(size_t)q * stride + ic];
     }
+  }
+  // lds: [ (kCoarseThreads/64) * K ]; one barrier inside
+  __device__ inline void reduce(double* lds, double (&out)[K], const double* __restrict__ part, int n, int stride) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       double sacc = 0.0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) sacc += r[q][u];
-      for (int i = threadIdx.x + U * kCoarseThreads; i < n; i += kCoarseThreads) sacc += part[(size_t)q * stride + i];
+      for (int u = 0; u < U; ++u) sacc += ((int)threadIdx.x + u * kCoarseThreads < n) ? r[q][u] : 0.0;
       v[q] = sacc;
     }
-  }
-  // lds: [ (kCoarseThreads/64) * K ]; one barrier inside
-  __device__ inline void reduce(double* lds, double (&out)[K]) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i0 = threadIdx.x + U * kCoarseThreads; i0 < n; i0 += 4 * kCoarseThreads) {  // large meshes only
+      double wv_[K][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < K; ++q) wv_[q][u] = part[(size_t)q * stride + min(i0 + u * kCoarseThreads, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] += (i0 + u * kCoarseThreads < n) ? wv_[q][u] : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
     if (lane == 0)
@@ -676,31 +689,63 @@ struct PartialSums {
   }
 };
 
-// Restriction partials part[slot][n] -> per-thread chunk sums for coarse dof d = t % n, chunk = t / n (3 chunks).
-struct SlotSums {
-  static constexpr int CH = 3, U = 16;
-  double acc;
-  __device__ inline void load(const double* __restrict__ part, int n, int slots) {
-    const int t = threadIdx.x, d = t % n, ch = t / n;
-    double r[U];
+// Restriction partials part[slot][n] of ONE aggregate g: 8 lanes per (array q, field f) sum the slots of coarse dof
+// g*NF+f; the workgroup of aggregate g needs nothing else of the partial arrays.
+template <int K, int NF>
+struct AggSlotSums {
+  static constexpr int L = 8, U = 6;  // lanes per dof, slots per lane requested up front (48 slots, then the tail loop)
+  double r[U];
+  const double* base;
+  __device__ inline void load(const double* const (&part)[K], int n, int slots, int g) {  // straight-line: requests only
+    const int t = threadIdx.x, combo = min(t / L, K * NF - 1), l = t & (L - 1);
+    const int q = combo / NF, f = combo - q * NF;
+    base = part[0];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int slot = ch + CH * u;
-      r[u] = (ch < CH && slot < slots) ? part[(size_t)slot * n + d] : 0.0;
+    for (int z = 1; z < K; ++z) base = (q == z) ? part[z] : base;
+    base += (size_t)g * NF + f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = base[(size_t)min(l + L * u, slots - 1) * n];
+  }
+  // lds[K*NF]; the caller synchronises
+  __device__ inline void to_lds(double* lds, int n, int slots) {
+    const int t = threadIdx.x, combo = t / L, l = t & (L - 1);
+    double v = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) v += (l + L * u < slots) ? r[u] : 0.0;
+    for (int s0 = l + L * U; s0 < slots; s0 += 4 * L) {  // large meshes only
+      double w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = base[(size_t)min(s0 + u * L, slots - 1) * n];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v += (s0 + u * L < slots) ? w[u] : 0.0;
     }
-    double sacc = 0.0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) sacc += r[u];
-    if (ch < CH)
-      for (int slot = ch + CH * U; slot < slots; slot += CH) sacc += part[(size_t)slot * n + d];
-    acc = sacc;
+    v += __shfl_xor(v, 1, L); v += __shfl_xor(v, 2, L); v += __shfl_xor(v, 4, L);
+    if (l == 0 && combo < K * NF) lds[combo] = v;
   }
-  __device__ inline void to_lds(double* lds /* [CH][kMaxCoarse] */, int n) const {
-    const int t = threadIdx.x, d = t % n, ch = t / n;
-    if (ch < CH) lds[ch * kMaxCoarse + d] = acc;
+};
+
+// yc of the coarse dofs a tile prolongs from = sum over the column-block partials yc[g][dof] the coarse workgroups
+// wrote: 8 lanes per dof (aggregate g = lane, lane + 8; nagg <= 16), kTileAggs*NF <= 64 dofs in one pass (padding
+// aggregates repeat aggregate 0).
+template <int NF>
+struct TileCoarse {
+  static constexpr int ROWS = kTileAggs * NF;
+  static_assert(ROWS * 8 <= kKrylovThreads, "one pass: 8 lanes per coarse dof of the tile");
+  double a0, a1;
+  int d;
+  __device__ inline void load(const Ctx& c, int tile) {  // straight-line: requests only
+    const int t = threadIdx.x, n = c.ncoarse, l = t & 7, rc = min(t >> 3, ROWS - 1);
+    const int ag = c.tile_aggs[tile * kTileAggs + rc / NF];
+    d = ag * NF + (rc - (rc / NF) * NF);
+    a0 = c.yc[(size_t)min(l, c.nagg - 1) * n + d];
+    a1 = c.yc[(size_t)min(l + 8, c.nagg - 1) * n + d];
   }
-  static __device__ inline double total(const double* lds, int d) {
-    return (lds[d] + lds[kMaxCoarse + d]) + lds[2 * kMaxCoarse + d];
+  // ycl[kMaxCoarse], indexed by the global coarse dof; the caller synchronises
+  __device__ inline void to_lds(const Ctx& c, double* ycl) {
+    const int t = threadIdx.x, l = t & 7;
+    double a = ((l < c.nagg) ? a0 : 0.0) + ((l + 8 < c.nagg) ? a1 : 0.0);
+    a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
+    if (l == 0 && (t >> 3) < ROWS) ycl[d] = a;
   }
 };
 
@@ -737,30 +782,31 @@ struct CoarseRows {
 };
 
 // Matrix part shared by the tile kernels: the wave's first PRE blocks are requested up front, x comes from LDS.
+// The preload is unconditional (vals / sell_lcol carry kRowPad block positions of zero padding behind the last
+// slice, positions past a short slice's end just read into the next slice) and masked afterwards.
 template <int NF>
 struct TileRows {
   static constexpr int PRE = GMPNP_ROW_PRELOAD;
   double av[PRE][NF];
   int lc[PRE];
-  int s, Iloc, i, cb, mx, w, row;
-  bool slice_ok, active;
+  int Iloc, i, cb, mx, w, row;
+  bool active;
   const double* base;
 
   __device__ inline void load(const Ctx& c, const double* __restrict__ vals, const TileRec& rec) {
     const int lane = threadIdx.x & 63;
     w = threadIdx.x >> 6;
-    s = 0; slice_ok = true;
     Iloc = lane / NF; i = lane - Iloc * NF;
     active = Iloc < rec.nn;
-    row = (rec.node0 + Iloc) * NF + i;
+    row = active ? (rec.node0 + Iloc) * NF + i : 0;
     cb = rec.colbase; mx = active ? rec.mx : 0; base = vals + rec.slice_off + lane;
+    const int il = min(Iloc, kSlicePad - 1);
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
       const int kp = w + u * kKrylovWaves;
-      const bool on = active && kp < mx;
-      lc[u] = on ? c.sell_lcol[(size_t)(cb + kp) * kSlicePad + Iloc] : 0;
+      lc[u] = c.sell_lcol[(size_t)(cb + kp) * kSlicePad + il];
 #pragma unroll
-      for (int j = 0; j < NF; ++j) av[u][j] = on ? base[(size_t)(kp * NF + j) * kWave] : 0.0;
+      for (int j = 0; j < NF; ++j) av[u][j] = base[(size_t)(kp * NF + j) * kWave];
     }
   }
 
@@ -768,9 +814,10 @@ struct TileRows {
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
-      const double* xv = xs + lc[u] * NF;
+      const bool on = w + u * kKrylovWaves < mx;
+      const double* xv = xs + (on ? lc[u] : 0) * NF;
 #pragma unroll
-      for (int j = 0; j < NF; ++j) acc += av[u][j] * xv[j];
+      for (int j = 0; j < NF; ++j) acc += (on ? av[u][j] : 0.0) * xv[j];
     }
     if (active) {
       for (int kp = w + PRE * kKrylovWaves; kp < mx; kp += kKrylovWaves) {  // rows with more than PRE*8 blocks
@@ -786,98 +833,120 @@ struct TileRows {
 
 constexpr int kStagePre = 2;  // staged x entries per thread requested up front (tiles with more columns: tail loop)
 
-// ---- coarse kernels: scalars of the half-iteration, coarse recurrences, yc = Aci * (P^T p  or  P^T s) ------------
-// Every workgroup redundantly reduces the per-tile partials (fixed order) and evaluates 8 rows of the coarse solve;
-// workgroup 0 publishes the scalars and the new coarse vectors for the following launches.
+#ifdef GMPNP_TIMING  // development builds only: phase timestamps (100 MHz clock) of three tiles behind the yc blocks
+#define GMPNP_STAMP(i) do { if (threadIdx.x == 0) { const int tq_ = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1)); \
+    if (tq_ >= 0) c.yc[kMaxCoarse * 16 + tq_ * 8 + (i)] = (double)wall_clock64(); } } while (0)
+#else
+#define GMPNP_STAMP(i) do { } while (0)
+#endif
+// Early exit of a finished solve.  The requested values get a (never executed) use on the exit path: without it the
+// compiler sinks every request below this branch, i.e. behind the scalar round trip that fetches the flag.
+#define GMPNP_EXIT_IF_DONE(flag, keep_expr) do { if (flag) { if (c.ndof < 0) c.yc[0] = (keep_expr); return; } } while (0)
+// ---- coarse kernels: scalars of the half-iteration, yc = Aci * (P^T p  or  P^T s) in column blocks ----------------
+// One workgroup per aggregate g.  It sums the per-tile restriction partials of ITS NF coarse dofs only (fixed order),
+// forms the NF entries of the coarse operand and writes the column-block product yc[g][:] = Aci[:, g-block] * operand_g;
+// the tile kernels add the nagg blocks for the few coarse dofs they prolong from (TileCoarse).  Every workgroup
+// reduces the scalar partials redundantly; workgroup 0 publishes the scalars.
 template <int NF>
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const int k) {
-  __shared__ double cs[4][SlotSums::CH * kMaxCoarse];
-  __shared__ double pcs[kMaxCoarse];
+  __shared__ double cs[4 * NF];
+  __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 4];
   KrylovScalars* sc = c.scal;
-  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, n = c.ncoarse;
+  const int t = threadIdx.x, n = c.ncoarse, g = blockIdx.x;
   const int par = k & 1;  // the iteration index comes from the host: no load stands in front of the requests below
   const bool first = (k == 0);
-  const int row = blockIdx.x * (kCoarseThreads / 64) + wv;
   // all requests first (the `done` flag among them: a finished solve still issues them, then exits)
+  GMPNP_STAMP(0);
   const int done_flag = sc->done;
-  double arow[3];
+  double acol[NF];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; arow[u] = (c.use_coarse && row < n && cc < n) ? c.Aci[(size_t)row * n + cc] : 0.0; }
+  for (int f = 0; f < NF; ++f) acol[f] = c.Aci[(size_t)min(t, n - 1) * n + g * NF + f];
   PartialSums<4> psum;
   // Exact restrictions of the ACTUAL fine vectors of iteration k-1 (epilogue partials of A(k-1) and B(k-1)): the
   // coarse vectors are rebuilt from them every iteration, nothing accumulates on the coarse level.
-  SlotSums sv_, st_, sr_, sp_;
-  if (!first) psum.load(c.part_b, c.ntiles, c.ntiles);
-  if (c.use_coarse) {
-    sv_.load(c.cpart_v[par ^ 1], n, c.tile_slots);  // P^T v_{k-1} (k = 0: P^T b from k_restrict)
-    if (!first) {
-      st_.load(c.cpart_t, n, c.tile_slots);          // P^T t_{k-1}
-      sr_.load(c.cpart_r[par ^ 1], n, c.tile_slots);  // P^T r_{k-1}
-      sp_.load(c.cpart_p[par ^ 1], n, c.tile_slots);  // P^T p_{k-1}
-    }
+  AggSlotSums<4, NF> ss;
+  psum.load(c.part_b, c.ntiles, c.ntiles);  // k = 0: stale values, not used
+  {  // P^T v_{k-1} (k = 0: P^T b from k_restrict), P^T t_{k-1}, P^T r_{k-1}, P^T p_{k-1}
+    const double* const arr[4] = {c.cpart_v[par ^ 1], first ? c.cpart_v[par ^ 1] : c.cpart_t,
+                                  first ? c.cpart_v[par ^ 1] : c.cpart_r[par ^ 1], first ? c.cpart_v[par ^ 1] : c.cpart_p[par ^ 1]};
+    ss.load(arr, n, c.tile_slots, g);
   }
+  const double sc_alpha = sc->alpha, sc_rho0 = sc->rho[0], sc_rho1 = sc->rho[1];
+  { double keep = ss.r[0];
+#pragma unroll
+    for (int u = 1; u < 6; ++u) keep += ss.r[u];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep += psum.r[q][0] + psum.r[q][1];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) keep += acol[f];
+    GMPNP_EXIT_IF_DONE(done_flag, keep); }
   double alpha = 0.0, rho_old = 1.0, rho_new = 0.0, omega = 0.0, beta = 0.0;
-  if (first) rho_new = sc->rho[1];  // the host puts (rhat, r_0) = ||b||^2 there
-  else { alpha = sc->alpha; rho_old = sc->rho[par ^ 1]; }
-  if (done_flag) return;
-  if (c.use_coarse) { sv_.to_lds(cs[0], n); if (!first) { st_.to_lds(cs[1], n); sr_.to_lds(cs[2], n); sp_.to_lds(cs[3], n); } }
+  if (first) rho_new = sc_rho1;  // the host puts (rhat, r_0) = ||b||^2 there
+  else { alpha = sc_alpha; rho_old = par ? sc_rho0 : sc_rho1; }
+  GMPNP_STAMP(1);
+  if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
+  GMPNP_STAMP(2);
   if (!first) {
     double tot[4];
-    psum.reduce(lred, tot);
+    psum.reduce(lred, tot, c.part_b, c.ntiles, c.ntiles);
     omega = tot[0] / tot[1];
     rho_new = tot[2] - omega * tot[3];
     beta = (rho_new / rho_old) * (alpha / omega);
   } else {
     __syncthreads();
   }
-  if (blockIdx.x == 0 && t == 0) { sc->omega = omega; sc->beta = beta; sc->rho[par] = rho_new; }
-  if (!c.use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
-  if (t < n) {
-    const double vc = SlotSums::total(cs[0], t);
+  GMPNP_STAMP(3);
+  if (g == 0 && t == 0) { sc->omega = omega; sc->beta = beta; sc->rho[par] = rho_new; }
+  if (!c.use_coarse) return;
+  if (t < NF) {
+    const double vc = cs[t];
     double rcn, pcn;
     if (first) { rcn = vc; pcn = vc; }
     else {
-      const double tc = SlotSums::total(cs[1], t), rc_old = SlotSums::total(cs[2], t), pc_old = SlotSums::total(cs[3], t);
+      const double tc = cs[NF + t], rc_old = cs[2 * NF + t], pc_old = cs[3 * NF + t];
       rcn = (rc_old - alpha * vc) - omega * tc;       // P^T r_k
       pcn = rcn + beta * (pc_old - omega * vc);       // P^T p_k
     }
     pcs[t] = pcn;
   }
   __syncthreads();
-  if (row >= n) return;
+  GMPNP_STAMP(4);
+  if (t >= n) return;
   double acc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; if (cc < n) acc += arow[u] * pcs[cc]; }
-  acc = wave_sum(acc);
-  if (lane == 0) c.yc[row] = acc;
+  for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
+  c.yc[(size_t)g * n + t] = acc;
+  GMPNP_STAMP(5);
 }
 
 template <int NF>
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) {
-  __shared__ double cs[2][SlotSums::CH * kMaxCoarse];
-  __shared__ double pcs[kMaxCoarse];
+  __shared__ double cs[2 * NF];
+  __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 2];
   KrylovScalars* sc = c.scal;
-  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, n = c.ncoarse;
+  const int t = threadIdx.x, n = c.ncoarse, g = blockIdx.x;
   const int par = k & 1;
   const int done_flag = sc->done, max_iters = sc->max_iters;
   const double rho_new = sc->rho[par], tol = sc->tol;
-  const int row = blockIdx.x * (kCoarseThreads / 64) + wv;
-  double arow[3];
+  double acol[NF];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; arow[u] = (c.use_coarse && row < n && cc < n) ? c.Aci[(size_t)row * n + cc] : 0.0; }
-  PartialSums<2> psum;
-  { PartialSums<1> pa, pr;
-    pa.load(c.part_a, c.ntiles, c.ntiles);
-    pr.load(c.part_rr, c.ntiles, c.ntiles);
-    psum.v[0] = pa.v[0]; psum.v[1] = pr.v[0]; }
-  SlotSums sv_, sr_;
-  if (c.use_coarse) { sv_.load(c.cpart_v[par], n, c.tile_slots); sr_.load(c.cpart_r[par], n, c.tile_slots); }
-  if (done_flag) return;
-  if (c.use_coarse) { sv_.to_lds(cs[0], n); sr_.to_lds(cs[1], n); }
+  for (int f = 0; f < NF; ++f) acol[f] = c.Aci[(size_t)min(t, n - 1) * n + g * NF + f];
+  PartialSums<2> psum;  // part_a and part_rr are adjacent halves of one buffer: stride ntiles
+  psum.load(c.part_a, c.ntiles, c.ntiles);
+  AggSlotSums<2, NF> ss;
+  { const double* const arr[2] = {c.cpart_v[par], c.cpart_r[par]}; ss.load(arr, n, c.tile_slots, g); }
+  { double keep = ss.r[0] + psum.r[0][0] + psum.r[1][0];
+#pragma unroll
+    for (int u = 1; u < 6; ++u) keep += ss.r[u];
+    keep += (psum.r[0][1] + psum.r[1][1]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) keep += acol[f];
+    GMPNP_EXIT_IF_DONE(done_flag, keep); }
+  if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
   double tot[2];
-  psum.reduce(lred, tot);
+  psum.reduce(lred, tot, c.part_a, c.ntiles, c.ntiles);
   const double rv = tot[0], rr = tot[1];
   int done = 0;
   if (!(rr == rr) || !(rv == rv)) done = 3;
@@ -886,17 +955,15 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const 
   else if (rv == 0.0 || rho_new == 0.0) done = 3;
   // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
   const double alpha = done ? 0.0 : rho_new / rv;
-  if (blockIdx.x == 0 && t == 0) { sc->alpha = alpha; sc->rr = rr; sc->done_next = done; }
-  if (done) return;
-  if (!c.use_coarse) { if (lane == 0 && row < n) c.yc[row] = 0.0; return; }
-  if (t < n) pcs[t] = SlotSums::total(cs[1], t) - alpha * SlotSums::total(cs[0], t);  // P^T s = P^T r_k - alpha P^T v_k
+  if (g == 0 && t == 0) { sc->alpha = alpha; sc->rr = rr; sc->done_next = done; }
+  if (done || !c.use_coarse) return;
+  if (t < NF) pcs[t] = cs[NF + t] - alpha * cs[t];  // P^T s = P^T r_k - alpha P^T v_k
   __syncthreads();
-  if (row >= n) return;
+  if (t >= n) return;
   double acc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int cc = lane + 64 * u; if (cc < n) acc += arow[u] * pcs[cc]; }
-  acc = wave_sum(acc);
-  if (lane == 0) c.yc[row] = acc;
+  for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
+  c.yc[(size_t)g * n + t] = acc;
 }
 
 // ---- fused half-iterations ------------------------------------------------------------------------------------
@@ -907,15 +974,20 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
   __shared__ double dpart[kSlicesPerTile][2];
   __shared__ double xs[kTileCols * NF];
+  __shared__ double ycl[kMaxCoarse];
+  __shared__ double own[6][64];
+  static_assert(kSlicesPerTile == 1 && NW >= 6, "own-row hand-over: one slice per tile, one wave per vector");
   KrylovScalars* sc = c.scal;
   const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int sl = wv / NW;
   const int par = k & 1, n = c.ncoarse;
   const bool first = (k == 0);
+  GMPNP_STAMP(0);
   const int done_flag = sc->done;
   const double alpha = sc->alpha, omega = sc->omega, beta = sc->beta;
   const double* __restrict__ po = c.kp[par ^ 1];
   const double* __restrict__ vo = c.kv[par ^ 1];
+  const double* __restrict__ sfirst = first ? c.kr : c.ks;  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
   // every global request of this launch, issued together
   // two independent chains: the tile record -> matrix values / local column indices, and the tile's column list
   // (fixed stride: addressable without the record) -> operands of the staged x entries
@@ -924,56 +996,61 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   int st_col[kStagePre], st_agg[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
-    const int cl = (t + u * kKrylovThreads) / NF;
-    const bool on = cl < c.col_stride;
-    st_col[u] = on ? c.tile_cols[c0 + cl] : 0; st_agg[u] = on ? c.tile_colslot[c0 + cl] : 0;
+    const int cl = min((t + u * kKrylovThreads) / NF, c.col_stride - 1);  // padding entries of the list point at node 0
+    st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
   }
+  TileCoarse<NF> tcs;
+  tcs.load(c, tile);
   TileRows<NF> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
-  double st_s[kStagePre], st_t[kStagePre], st_p[kStagePre], st_v[kStagePre], st_y[kStagePre];
+  double st_s[kStagePre], st_t[kStagePre], st_p[kStagePre], st_v[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    st_s[u] = st_t[u] = st_p[u] = st_v[u] = st_y[u] = 0.0;
-    if (q < c.col_stride * NF) {  // padding entries of the list point at node 0: harmless loads
-      const int cl = q / NF, f = q - cl * NF;
-      const size_t idx = (size_t)st_col[u] * NF + f;
-      st_y[u] = c.yc[st_agg[u] * NF + f];
-      if (first) st_s[u] = c.kr[idx];
-      else { st_s[u] = c.ks[idx]; st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx]; }
-    }
+    const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
+    st_s[u] = sfirst[idx]; st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx];  // k = 0: only st_s is used
   }
-  double own_s = 0.0, own_t = 0.0, own_p = 0.0, own_v = 0.0, own_y = 0.0, own_rh = 0.0;
-  int own_r = 0;
-  if (rows.w == 0 && rows.active) {
-    own_r = rows.row;
-    own_rh = c.krhat[own_r];
-    if (first) own_s = c.kr[own_r];
-    else { own_s = c.ks[own_r]; own_t = c.kt[own_r]; own_p = po[own_r]; own_v = vo[own_r]; own_y = c.ky[own_r]; }
-  }
-  if (done_flag) return;
+  // own rows (the epilogue of wave 0 needs six vectors at its rows): wave q requests vector q and hands it over through
+  // LDS, so that no load sits behind a branch and nobody holds six values
+  const int own_r = rows.row;  // inactive lanes: row 0
+  const double* ownp = wv == 0 ? c.krhat : wv == 1 ? sfirst : wv == 2 ? c.kt : wv == 3 ? po : wv == 4 ? vo : c.ky;
+  const double own_q = ownp[own_r];
+  { double keep = own_q + tcs.a0 + tcs.a1;
+#pragma unroll
+    for (int u = 0; u < kStagePre; ++u) keep += (st_s[u] + st_t[u]) + (st_p[u] + st_v[u]);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
+    GMPNP_EXIT_IF_DONE(done_flag, keep); }
+  GMPNP_STAMP(1);
+  const bool uc = c.use_coarse != 0;
+  if (uc) { tcs.to_lds(c, ycl); __syncthreads(); }
+  GMPNP_STAMP(2);
   // stage x = p_new + P yc for the tile's column nodes
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     if (q < nst) {
       const double pj = first ? st_s[u] : (st_s[u] - omega * st_t[u]) + beta * (st_p[u] - omega * st_v[u]);
-      xs[q] = pj + st_y[u];
+      xs[q] = pj + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
     }
   }
+  if (wv < 6) own[wv][lane] = own_q;
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
     const double pj = first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
-    xs[q] = pj + c.yc[c.tile_colslot[c0 + cl] * NF + f];
+    xs[q] = pj + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
+  GMPNP_STAMP(3);
   red[wv][lane] = rows.dot(c, xs);
   __syncthreads();
+  GMPNP_STAMP(4);
   // own rows, dots, partial restriction
   if (rows.w == 0) {
     double tot = 0.0, rn = 0.0, pn = 0.0;
+    const double own_rh = own[0][lane], own_s = own[1][lane], own_t = own[2][lane], own_p = own[3][lane], own_v = own[4][lane], own_y = own[5][lane];
     if (rows.active) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
@@ -1004,6 +1081,10 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
     for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
     c.part_a[tile] = a0; c.part_rr[tile] = a1;
   }
+#ifdef GMPNP_TIMING
+  __syncthreads();
+  GMPNP_STAMP(5);
+#endif
 }
 
 template <int NF>
@@ -1013,6 +1094,8 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
   __shared__ double outv[kSlicesPerTile][64];
   __shared__ double dpart[kSlicesPerTile][4];
   __shared__ double xs[kTileCols * NF];
+  __shared__ double ycl[kMaxCoarse];
+  __shared__ double own[3][64];
   KrylovScalars* sc = c.scal;
   const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int sl = wv / NW;
@@ -1025,51 +1108,53 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
   int st_col[kStagePre], st_agg[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
-    const int cl = (t + u * kKrylovThreads) / NF;
-    const bool on = cl < c.col_stride;
-    st_col[u] = on ? c.tile_cols[c0 + cl] : 0; st_agg[u] = on ? c.tile_colslot[c0 + cl] : 0;
+    const int cl = min((t + u * kKrylovThreads) / NF, c.col_stride - 1);  // padding entries of the list point at node 0
+    st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
   }
+  TileCoarse<NF> tcs;
+  tcs.load(c, tile);
   TileRows<NF> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
-  double st_r[kStagePre], st_v[kStagePre], st_y[kStagePre];
+  double st_r[kStagePre], st_v[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    st_r[u] = st_v[u] = st_y[u] = 0.0;
-    if (q < c.col_stride * NF) {
-      const int cl = q / NF, f = q - cl * NF;
-      const size_t idx = (size_t)st_col[u] * NF + f;
-      st_y[u] = c.yc[st_agg[u] * NF + f];
-      st_r[u] = c.kr[idx]; st_v[u] = vn[idx];
-    }
+    const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
+    st_r[u] = c.kr[idx]; st_v[u] = vn[idx];
   }
-  double own_r_ = 0.0, own_v = 0.0, own_rh = 0.0;
-  int own_r = 0;
-  if (rows.w == 0 && rows.active) {
-    own_r = rows.row;
-    own_r_ = c.kr[own_r]; own_v = vn[own_r]; own_rh = c.krhat[own_r];
-  }
-  if (done_flag) return;
+  const int own_r = rows.row;  // inactive lanes: row 0
+  const double* ownp = wv == 0 ? c.krhat : wv == 1 ? c.kr : vn;  // wave q requests own-row vector q (see k_bicg_a)
+  const double own_q = ownp[own_r];
+  { double keep = own_q + tcs.a0 + tcs.a1;
+#pragma unroll
+    for (int u = 0; u < kStagePre; ++u) keep += st_r[u] + st_v[u];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
+    GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (dn) {
     if (tile == 0 && t == 0) sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
     return;
   }
+  const bool uc = c.use_coarse != 0;
+  if (uc) { tcs.to_lds(c, ycl); __syncthreads(); }
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    if (q < nst) xs[q] = (st_r[u] - alpha * st_v[u]) + st_y[u];
+    if (q < nst) xs[q] = (st_r[u] - alpha * st_v[u]) + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
   }
+  if (wv < 3) own[wv][lane] = own_q;
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    xs[q] = (c.kr[idx] - alpha * vn[idx]) + c.yc[c.tile_colslot[c0 + cl] * NF + f];
+    xs[q] = (c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
   red[wv][lane] = rows.dot(c, xs);
   __syncthreads();
   if (rows.w == 0) {
     double tt = 0.0, sv = 0.0;
+    const double own_rh = own[0][lane], own_r_ = own[1][lane], own_v = own[2][lane];
     if (rows.active) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) tt += red[sl * NW + q][lane];

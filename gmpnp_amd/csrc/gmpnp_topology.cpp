@@ -101,7 +101,7 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
       for (int a = 0; a < nn; ++a) t.n2e[fill[t.cells[(size_t)e * nn + a]]++] = e * nn + a; }
 
   // ---- aggregates: contiguous, equal-count ranges of the internal order -------------------------
-  int nagg_max = kMaxCoarse / nf;  // and the LDS-resident block Gauss-Jordan must fit in 160 KiB
+  int nagg_max = std::min(kMaxCoarse / nf, 16);  // LDS-resident block Gauss-Jordan must fit in 160 KiB; TileCoarse sums <= 16 column blocks
   while (nagg_max > 1 && (size_t)((nagg_max * nf) * (nagg_max * nf) + nagg_max * nf * nf + 2 * nf * nf) * sizeof(double) > 160u * 1024u) --nagg_max;
   int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : nagg_max;
   nagg = std::max(1, std::min(nagg, nv / 8 > 0 ? nv / 8 : 1));
@@ -204,7 +204,7 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
   // distinct column nodes per tile (the Krylov kernels stage x for exactly these in LDS) and the tile-local index of
   // every block's column
   t.tile_colptr.assign(t.ntiles + 1, 0); t.tile_cols.clear(); t.tile_colslot.clear();
-  t.sell_lcol.assign((size_t)ncolrec * kSlicePad, 0);
+  t.sell_lcol.assign((size_t)(ncolrec + kRowPad) * kSlicePad, 0);  // + padding for the unconditional preload
   { std::vector<int> where(nv, -1), touched;
     for (int tl = 0; tl < t.ntiles; ++tl) {
       touched.clear();
