@@ -693,7 +693,7 @@ struct PartialSums {
 // g*NF+f; the workgroup of aggregate g needs nothing else of the partial arrays.
 template <int K, int NF>
 struct AggSlotSums {
-  static constexpr int L = 8, U = 6;  // lanes per dof, slots per lane requested up front (48 slots, then the tail loop)
+  static constexpr int L = 8, U = 9;  // lanes per dof, slots per lane requested up front (72 slots, then the tail loop)
   double r[U];
   const double* base;
   __device__ inline void load(const double* const (&part)[K], int n, int slots, int g) {  // straight-line: requests only
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const 
   const double sc_alpha = sc->alpha, sc_rho0 = sc->rho[0], sc_rho1 = sc->rho[1];
   { double keep = ss.r[0];
 #pragma unroll
-    for (int u = 1; u < 6; ++u) keep += ss.r[u];
+    for (int u = 1; u < 9; ++u) keep += ss.r[u];
 #pragma unroll
     for (int q = 0; q < 4; ++q) keep += psum.r[q][0] + psum.r[q][1];
 #pragma unroll
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const 
   { const double* const arr[2] = {c.cpart_v[par], c.cpart_r[par]}; ss.load(arr, n, c.tile_slots, g); }
   { double keep = ss.r[0] + psum.r[0][0] + psum.r[1][0];
 #pragma unroll
-    for (int u = 1; u < 6; ++u) keep += ss.r[u];
+    for (int u = 1; u < 9; ++u) keep += ss.r[u];
     keep += (psum.r[0][1] + psum.r[1][1]);
 #pragma unroll
     for (int f = 0; f < NF; ++f) keep += acol[f];

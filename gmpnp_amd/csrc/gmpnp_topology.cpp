@@ -103,7 +103,9 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
   // ---- aggregates: contiguous, equal-count ranges of the internal order -------------------------
   int nagg_max = std::min(kMaxCoarse / nf, 16);  // LDS-resident block Gauss-Jordan must fit in 160 KiB; TileCoarse sums <= 16 column blocks
   while (nagg_max > 1 && (size_t)((nagg_max * nf) * (nagg_max * nf) + nagg_max * nf * nf + 2 * nf * nf) * sizeof(double) > 160u * 1024u) --nagg_max;
-  int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : nagg_max;
+  // default: 8 slabs.  On the pore meshes 8..60 slabs give the same Krylov iteration count (the block-Jacobi smoother
+  // limits convergence, tools/precond_experiment.py), fewer than 8 lose it, and the coarse set-up cost grows with nagg^3.
+  int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : std::min(nagg_max, 8);
   nagg = std::max(1, std::min(nagg, nv / 8 > 0 ? nv / 8 : 1));
   if (fixed_nagg) nagg = nagg_req;
   for (;; --nagg) {  // shrink until no row touches more than kMaxRowAggs aggregates

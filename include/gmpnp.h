@@ -135,7 +135,7 @@ typedef struct {
 /* Creation-time tunables (no reference counterpart). Zero-initialise for defaults. */
 typedef struct {
   int32_t device_id;      /* HIP device ordinal */
-  int32_t n_aggregates;   /* coarse-space slabs; 0 = default (largest allowed by the LDS-resident coarse inverse) */
+  int32_t n_aggregates;   /* coarse-space slabs; 0 = default (8; at most 16 and what the LDS-resident coarse inverse allows) */
   int32_t use_graph;      /* reserved (the Krylov launches carry the iteration index as an argument: eager only) */
   int32_t krylov_batch;   /* iterations launched between convergence read-backs; 0 = default */
   int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */

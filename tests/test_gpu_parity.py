@@ -239,7 +239,7 @@ def test_full_size_properties(pore50, gpu_lib):
         r = np.array(st["residuals"])
         assert st["converged"] and np.all(r[2:] < r[1:-1])
         assert np.allclose(r[3:] / r[2:-1], 0.1, rtol=0.25)  # omega = 0.9: error x0.1 per iteration near the solution
-        assert a.n_aggregates == 15 and a.jacobian_nnz == 3931821
+        assert a.n_aggregates == 8 and a.jacobian_nnz == 3931821
 
 
 def test_dirichlet_and_model_updates(pore10, gpu_lib):
