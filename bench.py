@@ -19,7 +19,7 @@ Extra objects on the JSON line:
   roofline      dominant kernels = the two fused BiCGStab half-iterations k_bicg_a / k_bicg_b (one SELL block SpMV each plus
                 the vector updates).  achieved = algorithmic bytes of ONE SpMV (648 nb + 4 nb + 4 (nv+1) +
                 16 nd; the vector traffic fused in is not counted) / mean kernel duration, sampled LIVE during the timed
-                region: every 8th launch carries a start/stop HIP event pair attached to the dispatch itself
+                region: every 32nd launch carries a start/stop HIP event pair attached to the dispatch itself
                 (hipExtLaunchKernelGGL on the solver's stream), i.e. the kernel's own begin-to-end time.
   cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU, one thread) timed on rank 0 / N = 1 for ONE Newton
                 iteration of the same workload (about 20-30 s); kind = "port" (FEniCS itself cannot be installed).
@@ -97,7 +97,8 @@ def main():
 
     _, Lnm, _, Rnm = a.mesh.split("_")
     run = PoreRun(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine,
-                  device_kwargs={"device_id": local, "use_graph": False, "profile_every": 8})
+                  device_kwargs={"device_id": local, "use_graph": False,
+                                 "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "32"))})
     nv = run.mesh.num_vertices
 
     def reset():

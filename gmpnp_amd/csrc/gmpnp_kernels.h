@@ -27,8 +27,8 @@ struct Lay {
   static constexpr int O_IJ = O_EPS + 1;         // [NS] int u_i beta   (J rule)
   static constexpr int O_B = O_IJ + NS;          // [NN] int beta phi_b
   static constexpr int O_C = O_B + NN;           // [NS][NN] int u_i beta^2 phi_b
-  static constexpr int O_U = O_C + NS * NN;       // [NN][NS] nodal species values (bilinear reaction derivative)
-  static constexpr int EJ_STRIDE = O_U + NN * NS;
+  static constexpr int O_D = O_C + NS * NN;       // [MAX_BILINEAR][2][NN][NN] d(int u_x u_y phi_a)/d u_{x,b} and /d u_{y,b}
+  static constexpr int EJ_STRIDE = O_D + GMPNP_MAX_BILINEAR * 2 * NN * NN;
   static constexpr int EF_STRIDE = NN * NF;
   static constexpr double MDEN = 1.0 / ((DIM + 1) * (DIM + 2));  // M_ab = |K| (1+delta_ab) MDEN
   static constexpr double KAPPA = (DIM == 3) ? 1.0 / 120.0 : 1.0 / 24.0;  // d!/(d+3)!
@@ -229,6 +229,16 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
 #pragma unroll
     for (int a = 0; a < NN; ++a)
       mono[t][a] = vol * L::KAPPA * (Xs * Ys + xs[a] * Ys + Xs * ys[a] + D + 2.0 * xs[a] * ys[a]);
+    if constexpr (WANT_J) {  // derivative tables of the monomial: the Jacobian gather reads two numbers per term
+      double* dt = c.EJ + (size_t)e * L::EJ_STRIDE + L::O_D + t * 2 * NN * NN;
+#pragma unroll
+      for (int a = 0; a < NN; ++a)
+#pragma unroll
+        for (int b = 0; b < NN; ++b) {
+          dt[a * NN + b] = vol * L::KAPPA * (Ys + ys[a] + ys[b] + (a == b ? Ys + 2.0 * ys[a] : 0.0));            // d/d u_{bj,b}
+          dt[NN * NN + a * NN + b] = vol * L::KAPPA * (Xs + xs[a] + xs[b] + (a == b ? Xs + 2.0 * xs[a] : 0.0));  // d/d u_{bk,b}
+        }
+    }
   }
 #pragma unroll
   for (int a = 0; a < NN; ++a) {
@@ -272,10 +282,6 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
       for (int b = 0; b < NN; ++b) ej[L::O_C + j * NN + b] = Cq[j][b];
     }
     ej[L::O_EPS] = epsbar;
-#pragma unroll
-    for (int a = 0; a < NN; ++a)
-#pragma unroll
-      for (int j = 0; j < NS; ++j) ej[L::O_U + a * NS + j] = U[a][j];
   }
 }
 
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
 template <int DIM, int NF>
 __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
   using L = Lay<DIM, NF>;
-  constexpr int NS = L::NS, NN = L::NN, S = L::S;
+  constexpr int NS = L::NS, NN = L::NN, G = 2, MB = GMPNP_MAX_BILINEAR;
   const int wave = (blockIdx.x * kVecBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= c.n_work) return;
   const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
@@ -328,63 +334,84 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
   const int k = c.sell_blk[(size_t)(c.slice_colbase[s] + kpos) * kSlicePad + Iloc];
   if (k < 0) return;  // padding stays zero (set at create)
   const int J = c.cols[k];
+  const int qb = c.cptr[k], qend = c.cptr[k + 1];
+  const int bc = c.bcflag[I * NF + i];
   double* out = c.vals + c.slice_off[s] + (size_t)kpos * NF * kWave + lane;
-  if (c.bcflag[I * NF + i]) {  // [3P] DirichletBC.apply(A): identity row
-#pragma unroll
-    for (int j = 0; j < NF; ++j) out[j * kWave] = (J == I && j == i) ? 1.0 : 0.0;
-    return;
-  }
   const gmpnp_model_t& m = *c.model;
   const bool isp = (i == NS);
   const int is = isp ? 0 : i;
   const double zi = m.z[is], inv_dt = m.inv_dt;
-  double rc1i[NS];
+  double rc1i[NS], c2t[MB];
 #pragma unroll
   for (int j = 0; j < NS; ++j) rc1i[j] = m.rc1[is][j];
+#pragma unroll
+  for (int t = 0; t < MB; ++t) { const double v = m.rc2[is][t]; c2t[t] = (t < m.n_bilinear && !isp) ? v : 0.0; }
+  const int tmax = max(m.n_bilinear, 1) - 1;
+  const int qe = bc ? qb : qend;  // Dirichlet rows take no contributions
   double acc[NF];
 #pragma unroll
   for (int j = 0; j < NF; ++j) acc[j] = 0.0;
 
-#pragma unroll 4
-  for (int q = c.cptr[k]; q < c.cptr[k + 1]; ++q) {
-    const int pk = c.contrib[q];
-    const int e = pk >> 4, a = (pk >> 2) & 3, b = pk & 3;
-    const double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
-    const double vol = ej[L::O_VOL], ggab = ej[L::O_GG + a * NN + b], gpa = ej[L::O_GP + a];
-    const double Mab = vol * L::MDEN * (a == b ? 2.0 : 1.0), Kab = vol * ggab;
-    if (!isp) {
-      const double Gga = ej[L::O_GG_A + a];
-      const double ster = Gga * ej[L::O_C + is * NN + b] + ej[L::O_IJ + is] * ggab;
-      const double dg = inv_dt * Mab + Kab + zi * vol * (1.0 / NN) * gpa + Gga * ej[L::O_B + b];
+  // G contributions per trip; every value of a trip is requested before the first one is used (unconditional loads on
+  // clamped indices, masked by w = 0/1), and the contribution codes of the NEXT trip are requested with them: one
+  // memory round trip per trip instead of one per table.
+  int pk[G];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) acc[j] += m.a[j] * ster + rc1i[j] * Mab + (j == is ? dg : 0.0);
-      for (int t = 0; t < m.n_bilinear; ++t) {
-        const double c2 = m.rc2[is][t];
-        if (c2 != 0.0) {
-          const int bj = m.bil_j[t], bk = m.bil_k[t];
-          const double xa = ej[L::O_U + a * NS + bj], xb = ej[L::O_U + b * NS + bj];
-          const double ya = ej[L::O_U + a * NS + bk], yb = ej[L::O_U + b * NS + bk];
-          const double Xs = NN * ej[L::O_UBAR + bj], Ys = NN * ej[L::O_UBAR + bk];
-          const double w = c2 * vol * L::KAPPA;
-          const double dj = w * (Ys + ya + yb + (a == b ? Ys + 2.0 * ya : 0.0));  // d/d u_{bj,b}
-          const double dk = w * (Xs + xa + xb + (a == b ? Xs + 2.0 * xa : 0.0));  // d/d u_{bk,b}
+  for (int u = 0; u < G; ++u) pk[u] = c.contrib[max(min(qb + u, qe - 1), 0)];
+  for (int q0 = qb; q0 < qe; q0 += G) {
+    double vol[G], ggab[G], gpa[G], gga[G], cq[G], ij[G], bq[G], ub[G], ep[G], dj[G][MB], dk[G][MB];
+    int pa[G], pb[G];
 #pragma unroll
-          for (int j = 0; j < NS; ++j) acc[j] += (j == bj ? dj : 0.0) + (j == bk ? dk : 0.0);
-        }
+    for (int u = 0; u < G; ++u) {
+      const int e = pk[u] >> 4, a = (pk[u] >> 2) & 3, b = pk[u] & 3;
+      const double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
+      pa[u] = a; pb[u] = b;
+      vol[u] = ej[L::O_VOL]; ggab[u] = ej[L::O_GG + a * NN + b]; gpa[u] = ej[L::O_GP + a]; gga[u] = ej[L::O_GG_A + a];
+      cq[u] = ej[L::O_C + is * NN + b]; ij[u] = ej[L::O_IJ + is]; bq[u] = ej[L::O_B + b]; ub[u] = ej[L::O_UBAR + is];
+      ep[u] = ej[L::O_EPS];
+#pragma unroll
+      for (int t = 0; t < MB; ++t) {
+        const double* dt = ej + L::O_D + min(t, tmax) * 2 * NN * NN + a * NN + b;
+        dj[u][t] = dt[0]; dk[u][t] = dt[NN * NN];
       }
-      acc[NS] += zi * ej[L::O_UBAR + is] * Kab;
-    } else {
-      const double kpa = vol * gpa * (1.0 / NN);
-#pragma unroll
-      for (int j = 0; j < NS; ++j) acc[j] += -m.epsc[j] * kpa + m.qzb[j] * Mab;
-      acc[NS] += -ej[L::O_EPS] * Kab;
     }
+    int pkn[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) pkn[u] = c.contrib[max(min(q0 + G + u, qe - 1), 0)];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const double w = (q0 + u < qe) ? 1.0 : 0.0;
+      const double Mab = vol[u] * L::MDEN * (pa[u] == pb[u] ? 2.0 : 1.0), Kab = vol[u] * ggab[u];
+      if (!isp) {
+        const double ster = gga[u] * cq[u] + ij[u] * ggab[u];
+        const double dg = inv_dt * Mab + Kab + zi * vol[u] * (1.0 / NN) * gpa[u] + gga[u] * bq[u];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          double term = m.a[j] * ster + rc1i[j] * Mab + (j == is ? dg : 0.0);
+#pragma unroll
+          for (int t = 0; t < MB; ++t)  // c2t = 0 beyond n_bilinear
+            term += (j == m.bil_j[t] ? c2t[t] * dj[u][t] : 0.0) + (j == m.bil_k[t] ? c2t[t] * dk[u][t] : 0.0);
+          acc[j] += w * term;
+        }
+        acc[NS] += w * (zi * ub[u] * Kab);
+      } else {
+        const double kpa = vol[u] * gpa[u] * (1.0 / NN);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) acc[j] += w * (-m.epsc[j] * kpa + m.qzb[j] * Mab);
+        acc[NS] += w * (-ep[u] * Kab);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) pk[u] = pkn[u];
+  }
+  if (bc) {  // [3P] DirichletBC.apply(A): identity row
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[j] = (J == I && j == i) ? 1.0 : 0.0;
   }
 #pragma unroll
   for (int j = 0; j < NF; ++j) out[j * kWave] = acc[j];
 }
 
-// Robin (exit) mass entries, one lane per pre-merged entry (unique addresses: no atomics).
 __global__ void k_robin_add(const Ctx c) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= c.n_robin) return;

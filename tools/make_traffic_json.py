@@ -1,0 +1,33 @@
+"""Combine two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 3 --warmup 1` into
+profiles/r01/bench_steps3_pmc_fetch_write.json (all kernels) and profiles/r01_spmv_pmc.json (the roofline kernels;
+bench.py reads `hbm_bytes_per_launch` from it).
+
+  python tools/pmc_summary.py gpurun_out/pmc_fetch > gpurun_out/pmc_fetch.json
+  python tools/pmc_summary.py gpurun_out/pmc_write > gpurun_out/pmc_write.json
+  python tools/make_traffic_json.py gpurun_out/pmc_fetch.json gpurun_out/pmc_write.json
+"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+fetch = json.load(open(sys.argv[1]))
+write = json.load(open(sys.argv[2]))
+out = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}
+for name, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+    for k, cs in d.items():
+        if name in cs:
+            out[name][k] = {"launches": cs[name]["launches"], "median_KB": cs[name]["median"], "mean_KB": cs[name]["mean"]}
+os.makedirs(os.path.join(ROOT, "profiles", "r01"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01", "bench_steps3_pmc_fetch_write.json"), "w"), indent=1)
+
+def per_launch(kernel):
+    f = [v for k, v in out["FETCH_SIZE"].items() if kernel in k][0]["mean_KB"]
+    w = [v for k, v in out["WRITE_SIZE"].items() if kernel in k][0]["mean_KB"]
+    return 2.0 * f * 1024.0 + w * 1024.0
+
+a, b = per_launch("k_bicg_a<9>"), per_launch("k_bicg_b<9>")
+json.dump({
+    "source": "profiles/r01/bench_steps3_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 1`)",
+    "correction": "bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024; the factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM / rocprofv3 section), calibrated here for the solver's own access width (tools/calib_fetch.hip: a 2 GiB stream read with 8 B per lane / 63 active lanes reports FETCH_SIZE*1024 = 0.500005 of the bytes, same as 16 B per lane)",
+    "k_bicg_a_bytes_per_launch": a, "k_bicg_b_bytes_per_launch": b, "hbm_bytes_per_launch": 0.5 * (a + b),
+    "note": "memory-side (L2 miss) traffic; Infinity-Cache hits are included in FETCH_SIZE, so this is an upper bound on HBM bytes for this < 60 MB working set",
+}, open(os.path.join(ROOT, "profiles", "r01_spmv_pmc.json"), "w"), indent=1)
+print("k_bicg_a %.2f MB, k_bicg_b %.2f MB per launch" % (a / 1e6, b / 1e6))
