@@ -11,9 +11,10 @@ median -> Sechenov -> new Dirichlet value, u_n.assign(u)).  W warm-up steps run 
 t = 0), then EXACTLY K steps from t = 0 are timed between barrier + synchronize pairs; value = Newton iterations of
 all ranks / max-over-ranks time.
 
-N > 1 (this round): one independent L_50_R_5 problem per GPU (the parameter-sweep mapping of BASELINE configs[4],
-"replicas only", no data-path collective) -> weak scaling.  The mesh-partitioned single-problem solve with RCCL halo
-exchange is not wired into this bench yet (multi-GPU).
+N > 1: one independent L_50_R_5 problem per GPU (the parameter-sweep mapping of BASELINE configs[4], "replicas
+only", no data-path collective) -> weak scaling.  The mesh-partitioned single-problem solve exists (gmpnp_amd/dist.py,
+tested at world_size 2) but cannot beat one GPU on a 3.7k-vertex mesh, so it is not what this
+bench times.
 
 Extra objects on the JSON line:
   roofline      dominant kernels = the two fused BiCGStab half-iterations k_bicg_a / k_bicg_b (one SELL block SpMV each plus
