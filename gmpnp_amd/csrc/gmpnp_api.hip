@@ -401,9 +401,6 @@ int build_tridiagonal(gmpnp_solver* s) {
     l.Li = take((size_t)nf * nf * n); l.Ui = take((size_t)nf * nf * n); l.bi = take((size_t)nf * n); l.x = take((size_t)nf * n);
     s->tri.push_back(l);
   }
-  const int lds = nf * (3 * nf + 1) * 64 * (int)sizeof(double);
-  HIP_TRY(hipFuncSetAttribute((const void*)k_bcr_forward<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_bcr_top<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   s->tri_ok = true;
   return GMPNP_OK;
 }
@@ -412,14 +409,13 @@ int build_tridiagonal(gmpnp_solver* s) {
 template <int NF>
 int tri_solve(gmpnp_solver* s, const double* rhs) {
   if (!s->tri_ok) return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh in path order");
-  const size_t lds = (size_t)NF * (3 * NF + 1) * 64 * sizeof(double);
   hipLaunchKernelGGL((k_tri_extract<NF>), dim3(grid_for(s->t.nv * NF * NF, kVecBlock)), dim3(kVecBlock), 0, s->stream,
                      s->c, s->tri[0], s->tri_kpos.p, rhs);
   const int nl = (int)s->tri.size();
   for (int l = 0; l + 1 < nl; ++l)
-    hipLaunchKernelGGL((k_bcr_forward<NF>), dim3(grid_for(s->tri[l + 1].n, 64)), dim3(64), lds, s->stream, s->tri[l],
+    hipLaunchKernelGGL((k_bcr_forward<NF>), dim3(grid_for(s->tri[l + 1].n, 4)), dim3(64), 0, s->stream, s->tri[l],
                        s->tri[l + 1], s->status.p);
-  hipLaunchKernelGGL((k_bcr_top<NF>), dim3(1), dim3(64), lds, s->stream, s->tri[nl - 1], s->status.p);
+  hipLaunchKernelGGL((k_bcr_top<NF>), dim3(1), dim3(64), 0, s->stream, s->tri[nl - 1], s->status.p);
   for (int l = nl - 2; l >= 0; --l)
     hipLaunchKernelGGL((k_bcr_backward<NF>), dim3(grid_for(s->tri[l].n, kVecBlock)), dim3(kVecBlock), 0, s->stream,
                        s->tri[l], s->tri[l + 1]);

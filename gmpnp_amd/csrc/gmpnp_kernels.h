@@ -1353,79 +1353,104 @@ struct TriLevel {
   double* x;                 // [NF][n]
 };
 
-// Solve Dm X = [Lm | Um | bm] for row j of level lv; result left in W[(r*(3*NF+1) + NF + c)*64 + t], c in [0, 2NF].
+// Solve Dm X = [Lm | Um | bm] for row j of level lv with EIGHT LANES per system: lane r (< NF) of the 8-lane group
+// holds row r of the augmented matrix in registers, W[0..NF) = Dm row, W[NF..NC) = right-hand sides.  Gauss-Jordan
+// with partial pivoting; pivot search and row broadcasts are shuffles inside the group.  On return W[NF..NC) of
+// lane r is row r of Dm^{-1}[Lm | Um | bm].  Every lane of the wave must call it (inactive groups pass on = false).
 template <int NF>
-__device__ inline bool tri_inv_apply(const TriLevel& lv, int j, double* W, int t) {
+__device__ inline bool tri_group_solve(const TriLevel& lv, int j, bool on, int r, double (&W)[3 * NF + 1]) {
   constexpr int NC = 3 * NF + 1;
-  for (int r = 0; r < NF; ++r) {
-    for (int cI = 0; cI < NF; ++cI) {
-      W[(r * NC + cI) * 64 + t] = lv.D[(size_t)(r * NF + cI) * lv.n + j];
-      W[(r * NC + NF + cI) * 64 + t] = lv.L[(size_t)(r * NF + cI) * lv.n + j];
-      W[(r * NC + 2 * NF + cI) * 64 + t] = lv.U[(size_t)(r * NF + cI) * lv.n + j];
-    }
-    W[(r * NC + 3 * NF) * 64 + t] = lv.b[(size_t)r * lv.n + j];
+  const bool rowon = on && r < NF;
+  const int jc = on ? j : 0, rc = r < NF ? r : 0;
+#pragma unroll
+  for (int cI = 0; cI < NF; ++cI) {
+    const size_t off = (size_t)(rc * NF + cI) * lv.n + jc;
+    W[cI] = lv.D[off]; W[NF + cI] = lv.L[off]; W[2 * NF + cI] = lv.U[off];
   }
+  W[3 * NF] = lv.b[(size_t)rc * lv.n + jc];
+  if (!rowon) {  // identity row: never chosen as a pivot for another row, harmless in the shuffles
+#pragma unroll
+    for (int cI = 0; cI < NC; ++cI) W[cI] = (cI == r && r < NF) ? 1.0 : 0.0;
+  }
+  bool bad = false;
+#pragma unroll
   for (int k = 0; k < NF; ++k) {
-    int p = k; double best = fabs(W[(k * NC + k) * 64 + t]);
-    for (int r = k + 1; r < NF; ++r) { const double v = fabs(W[(r * NC + k) * 64 + t]); if (v > best) { best = v; p = r; } }
-    if (!(best > 0.0)) return false;
-    if (p != k)
-      for (int cI = k; cI < NC; ++cI) { const double tmp = W[(k * NC + cI) * 64 + t]; W[(k * NC + cI) * 64 + t] = W[(p * NC + cI) * 64 + t]; W[(p * NC + cI) * 64 + t] = tmp; }
-    const double ip = 1.0 / W[(k * NC + k) * 64 + t];
-    for (int cI = k; cI < NC; ++cI) W[(k * NC + cI) * 64 + t] *= ip;
-    for (int r = 0; r < NF; ++r) {
-      if (r == k) continue;
-      const double f = W[(r * NC + k) * 64 + t];
-      if (f == 0.0) continue;
-      for (int cI = k; cI < NC; ++cI) W[(r * NC + cI) * 64 + t] -= f * W[(k * NC + cI) * 64 + t];
+    double v = (r < NF && r >= k) ? fabs(W[k]) : -1.0; int idx = r;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 8); const int oi = __shfl_xor(idx, o, 8);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
+    bad |= !(v > 0.0);
+    // rows k and idx swap places (lane k takes the pivot row, lane idx the old row k), then scale / eliminate
+    const double ip = 1.0 / __shfl(W[k], idx, 8);
+    const double oldk_k = __shfl(W[k], k, 8);
+    const double f = ((r == idx) ? oldk_k : W[k]) * ip;
+#pragma unroll
+    for (int cI = k + 1; cI < NC; ++cI) {
+      const double from_p = __shfl(W[cI], idx, 8), from_k = __shfl(W[cI], k, 8);
+      const double mine = (r == idx) ? from_k : W[cI];
+      W[cI] = (r == k) ? from_p * ip : mine - f * from_p;
+    }
+    W[k] = (r == k) ? 1.0 : 0.0;  // column k is done (keeps later pivot searches of lanes < k out via r >= k anyway)
   }
-  return true;
+  return !(on && bad);
 }
 
+// One level of the reduction.  16 lanes per row ih of the upper level: lanes 0-7 eliminate the left neighbour
+// (row 2ih-1 of the lower level), lanes 8-15 the right one (2ih+1); lane r of each half owns row r of the 7x7 blocks.
 template <int NF>
 __global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, int32_t* status) {
   constexpr int NC = 3 * NF + 1;
-  extern __shared__ double W[];  // [NF*NC][64]
-  const int t = threadIdx.x, ih = blockIdx.x * 64 + t;  // row of the upper level
-  if (ih >= hi.n) return;
-  const int i = 2 * ih;
-  bool ok = true;
-  // start from row i itself
-  for (int e = 0; e < NF * NF; ++e) {
-    hi.D[(size_t)e * hi.n + ih] = lo.D[(size_t)e * lo.n + i];
-    hi.L[(size_t)e * hi.n + ih] = 0.0;
-    hi.U[(size_t)e * hi.n + ih] = 0.0;
+  const int t = threadIdx.x, ih_raw = blockIdx.x * 4 + (t >> 4);
+  const int side = (t >> 3) & 1, r = t & 7;
+  const bool rowok = ih_raw < hi.n;
+  const int ih = rowok ? ih_raw : 0, i = 2 * ih;
+  const int j = side == 0 ? i - 1 : i + 1;
+  const bool on = rowok && j >= 0 && j < lo.n;
+  const int rc = r < NF ? r : 0;
+  double W[NC];
+  // coupling of row i to row j: row r of lo.L (left) / lo.U (right); own row of lo.D and lo.b
+  double cr[NF], dr[NF];
+  const double* C = side == 0 ? lo.L : lo.U;
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI) { cr[mI] = C[(size_t)(rc * NF + mI) * lo.n + i]; dr[mI] = lo.D[(size_t)(rc * NF + mI) * lo.n + i]; }
+  const double br = lo.b[(size_t)rc * lo.n + i];
+  const bool ok = tri_group_solve<NF>(lo, j, on, r, W);
+  // products C * X: X row m sits in lane m of this half
+  double pL[NF], pU[NF], pb = 0.0;
+#pragma unroll
+  for (int cI = 0; cI < NF; ++cI) { pL[cI] = 0.0; pU[cI] = 0.0; }
+#pragma unroll
+  for (int mI = 0; mI < NF; ++mI) {
+    const double cm = on ? cr[mI] : 0.0;
+#pragma unroll
+    for (int cI = 0; cI < NF; ++cI) { pL[cI] += cm * __shfl(W[NF + cI], mI, 8); pU[cI] += cm * __shfl(W[2 * NF + cI], mI, 8); }
+    pb += cm * __shfl(W[3 * NF], mI, 8);
   }
-  for (int r = 0; r < NF; ++r) hi.b[(size_t)r * hi.n + ih] = lo.b[(size_t)r * lo.n + i];
-  for (int side = 0; side < 2; ++side) {
-    const int j = side == 0 ? i - 1 : i + 1;
-    if (j < 0 || j >= lo.n) continue;
-    ok &= tri_inv_apply<NF>(lo, j, W, t);
-    const double* C = side == 0 ? lo.L : lo.U;  // coupling of row i to row j
-    for (int r = 0; r < NF; ++r) {
-      double cr[NF];
+  // the diagonal block and the right-hand side take a term from both halves
+  double dmine[NF], dother[NF];
 #pragma unroll
-      for (int mI = 0; mI < NF; ++mI) cr[mI] = C[(size_t)(r * NF + mI) * lo.n + i];
+  for (int cI = 0; cI < NF; ++cI) { dmine[cI] = side == 0 ? pU[cI] : pL[cI]; dother[cI] = __shfl_xor(dmine[cI], 8, 16); }
+  const double pbo = __shfl_xor(pb, 8, 16);
+  if (rowok && r < NF) {
+    if (side == 0) {
+#pragma unroll
       for (int cI = 0; cI < NF; ++cI) {
-        double sL = 0.0, sU = 0.0;
-#pragma unroll
-        for (int mI = 0; mI < NF; ++mI) { sL += cr[mI] * W[(mI * NC + NF + cI) * 64 + t]; sU += cr[mI] * W[(mI * NC + 2 * NF + cI) * 64 + t]; }
-        if (side == 0) { hi.L[(size_t)(r * NF + cI) * hi.n + ih] = -sL; hi.D[(size_t)(r * NF + cI) * hi.n + ih] -= sU; }
-        else { hi.D[(size_t)(r * NF + cI) * hi.n + ih] -= sL; hi.U[(size_t)(r * NF + cI) * hi.n + ih] = -sU; }
+        hi.L[(size_t)(r * NF + cI) * hi.n + ih] = -pL[cI];
+        hi.D[(size_t)(r * NF + cI) * hi.n + ih] = (dr[cI] - dmine[cI]) - dother[cI];  // left term first, then right
       }
-      double sb = 0.0;
+    } else {
 #pragma unroll
-      for (int mI = 0; mI < NF; ++mI) sb += cr[mI] * W[(mI * NC + 3 * NF) * 64 + t];
-      hi.b[(size_t)r * hi.n + ih] -= sb;
-    }
-    if (side == 1) {  // keep the right neighbour's solved couplings for the way back up
-      for (int r = 0; r < NF; ++r) {
+      for (int cI = 0; cI < NF; ++cI) hi.U[(size_t)(r * NF + cI) * hi.n + ih] = -pU[cI];
+      hi.b[(size_t)r * hi.n + ih] = (br - pbo) - pb;
+      if (on) {  // keep the right neighbour's solved couplings for the way back up
+#pragma unroll
         for (int cI = 0; cI < NF; ++cI) {
-          lo.Li[(size_t)(r * NF + cI) * lo.n + j] = W[(r * NC + NF + cI) * 64 + t];
-          lo.Ui[(size_t)(r * NF + cI) * lo.n + j] = W[(r * NC + 2 * NF + cI) * 64 + t];
+          lo.Li[(size_t)(r * NF + cI) * lo.n + j] = W[NF + cI];
+          lo.Ui[(size_t)(r * NF + cI) * lo.n + j] = W[2 * NF + cI];
         }
-        lo.bi[(size_t)r * lo.n + j] = W[(r * NC + 3 * NF) * 64 + t];
+        lo.bi[(size_t)r * lo.n + j] = W[3 * NF];
       }
     }
   }
@@ -1435,11 +1460,12 @@ __global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, in
 // top of the pyramid: one row, x = D^{-1} b
 template <int NF>
 __global__ __launch_bounds__(64) void k_bcr_top(TriLevel top, int32_t* status) {
-  extern __shared__ double W[];
   constexpr int NC = 3 * NF + 1;
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!tri_inv_apply<NF>(top, 0, W, 0)) { atomicOr(status, 2); return; }
-  for (int r = 0; r < NF; ++r) top.x[r] = W[(r * NC + 3 * NF) * 64];
+  const int t = threadIdx.x, r = t & 7;
+  double W[NC];
+  const bool ok = tri_group_solve<NF>(top, 0, t < 8, r, W);
+  if (t < NF) top.x[t] = W[3 * NF];
+  if (!ok) atomicOr(status, 2);
 }
 
 template <int NF>
