@@ -422,48 +422,48 @@ __global__ void k_robin_add(const Ctx c) {
 // ---------------------------------------------------------------------------------------------
 // Node-block Jacobi: invert the NF x NF diagonal blocks (Gauss-Jordan, partial pivoting, LDS-resident).
 // ---------------------------------------------------------------------------------------------
+// Dinv = inverse of the diagonal node blocks.  16 lanes per node: lane r (< NF) holds row r of [A | I] in registers;
+// Gauss-Jordan with partial pivoting, pivot search and row broadcasts by shuffles inside the 16-lane group.
 template <int NF>
 __global__ __launch_bounds__(64) void k_block_inverse(const Ctx c) {
-  constexpr int S = kWave / NF;
-  __shared__ double A[NF * NF][64];
-  const int I = blockIdx.x * 64 + threadIdx.x, t = threadIdx.x;
-  if (I >= c.nv) return;
+  const int t = threadIdx.x, r = t & 15, I_raw = blockIdx.x * 4 + (t >> 4);
+  const bool on = I_raw < c.nv;
+  const int I = on ? I_raw : 0, rc = r < NF ? r : 0;
   const int s = c.node_slice[I], Iloc = I - c.slice_node0[s];
-  const double* base = c.vals + c.slice_off[s] + Iloc * NF;  // the diagonal block is SELL position 0
-  for (int i = 0; i < NF; ++i)
-    for (int j = 0; j < NF; ++j) A[i * NF + j][t] = base[(size_t)j * kWave + i];
-  int piv[NF];
-  bool sing = false;
+  const double* base = c.vals + c.slice_off[s] + Iloc * NF + rc;  // the diagonal block is SELL position 0
+  double row[2 * NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) { const double v = base[(size_t)j * kWave]; row[j] = (r < NF) ? v : 0.0; row[NF + j] = (j == r) ? 1.0 : 0.0; }
+  bool bad = false;
+#pragma unroll
   for (int k = 0; k < NF; ++k) {
-    int p = k; double best = fabs(A[k * NF + k][t]);
-    for (int r = k + 1; r < NF; ++r) { const double v = fabs(A[r * NF + k][t]); if (v > best) { best = v; p = r; } }
-    piv[k] = p;
-    if (!(best > 0.0)) { sing = true; break; }
-    if (p != k)
-      for (int j = 0; j < NF; ++j) { const double tmp = A[k * NF + j][t]; A[k * NF + j][t] = A[p * NF + j][t]; A[p * NF + j][t] = tmp; }
-    const double ip = 1.0 / A[k * NF + k][t];
-    A[k * NF + k][t] = 1.0;
-    for (int j = 0; j < NF; ++j) A[k * NF + j][t] *= ip;
-    for (int r = 0; r < NF; ++r) {
-      if (r == k) continue;
-      const double f = A[r * NF + k][t];
-      A[r * NF + k][t] = 0.0;
-      for (int j = 0; j < NF; ++j) A[r * NF + j][t] -= f * A[k * NF + j][t];
+    double v = (r < NF && r >= k) ? fabs(row[k]) : -1.0; int idx = r;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 16); const int oi = __shfl_xor(idx, o, 16);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
+    bad |= !(v > 0.0);
+    // rows k and idx swap places (lane k takes the pivot row, lane idx the old row k), then scale / eliminate
+    const double ip = 1.0 / __shfl(row[k], idx, 16);
+    const double oldk_k = __shfl(row[k], k, 16);
+    const double f = ((r == idx) ? oldk_k : row[k]) * ip;
+#pragma unroll
+    for (int j = k + 1; j < 2 * NF; ++j) {
+      const double from_p = __shfl(row[j], idx, 16), from_k = __shfl(row[j], k, 16);
+      const double mine = (r == idx) ? from_k : row[j];
+      row[j] = (r == k) ? from_p * ip : mine - f * from_p;
+    }
+    row[k] = (r == k) ? 1.0 : 0.0;
   }
-  if (sing) { atomicOr(c.status, 2); return; }
-  for (int k = NF - 1; k >= 0; --k)
-    if (piv[k] != k)
-      for (int r = 0; r < NF; ++r) { const double tmp = A[r * NF + k][t]; A[r * NF + k][t] = A[r * NF + piv[k]][t]; A[r * NF + piv[k]][t] = tmp; }
-  double* o = c.Dinv + (size_t)I * NF * NF;
-  for (int q = 0; q < NF * NF; ++q) o[q] = A[q][t];
+  if (on && bad) { atomicOr(c.status, 2); }
+  if (on && r < NF) {
+    double* o = c.Dinv + ((size_t)I * NF + r) * NF;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) o[j] = row[NF + j];
+  }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Coarse operator Ac = P^T A P in two deterministic stages.
-//   stage 1 (k_coarse_rows): AP[r][slot][j] = sum over the row's blocks whose column node lies in aggregate slot
-//   stage 2 (k_coarse_sum) : Ac[g*NF+i][h*NF+j] = sum over nodes I in g of AP[(I,i)][slot(h)][j]
-// ---------------------------------------------------------------------------------------------
 template <int NF>
 __global__ __launch_bounds__(64) void k_coarse_rows(const Ctx c) {
   constexpr int S = kWave / NF;
@@ -1291,9 +1291,15 @@ __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, cons
   const int tile = blockIdx.x, t = threadIdx.x;
   int own_slot = 0;
   if (c.use_coarse) {
-    if (t < c.ncoarse) {
+    if (t < c.ncoarse) {  // fixed-order sum over the slots, eight requests in flight at a time
       double sacc = 0.0;
-      for (int q = 0; q < c.tile_slots; ++q) sacc += part[(size_t)q * c.ncoarse + t];
+      for (int q0 = 0; q0 < c.tile_slots; q0 += 8) {
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = part[(size_t)min(q0 + u, c.tile_slots - 1) * c.ncoarse + t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += (q0 + u < c.tile_slots) ? w[u] : 0.0;
+      }
       pcs[t] = sacc;
     }
     __syncthreads();
@@ -1329,6 +1335,23 @@ __global__ __launch_bounds__(256) void k_stream_read(const double2* __restrict__
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) { const double2 v = a[i]; acc += v.x + v.y; }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0 && acc == 123.456) out[blockIdx.x] = acc;
+}
+
+// True residual of a finished Krylov solve: r = b - Ax (Ax from k_spmv_plain), per-workgroup partials of ||r||^2.
+__global__ __launch_bounds__(kVecBlock) void k_true_residual(const double* __restrict__ b, const double* __restrict__ ax,
+                                                             double* __restrict__ r, double* __restrict__ part, int n) {
+  __shared__ double lds[4];
+  const int i = blockIdx.x * kVecBlock + threadIdx.x;
+  double v = 0.0;
+  if (i < n) { v = b[i] - ax[i]; r[i] = v; }
+  double w[1] = {v * v};
+  block_sum<1>(w, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = w[0];
+}
+
+__global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, double a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
 }
 
 __global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {
