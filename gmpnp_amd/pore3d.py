@@ -57,6 +57,7 @@ class PoreRun:
         # history rows: initial ones/zeros (3D:771-779), one row appended per step (3D:842-850)
         self.history = [np.concatenate([np.ones((nv, 8)), np.zeros((nv, 1))], axis=1)]
         self.CO2_min = None
+        self.co2_bc = None  # CO2 Dirichlet value in force (None = the equilibrium value of the set-up)
         self.n = 0
         self.t = 0.0
         self.newton_its = []
@@ -68,6 +69,7 @@ class PoreRun:
         # medians of the scaled ion concentrations -> Sechenov -> new CO2 Dirichlet value at S1 (3D:817-838)
         co2 = self.pp.sechenov_co2_scaled(np.median(vals[:, 1]), np.median(vals[:, 2]), np.median(vals[:, 3]),
                                           np.median(vals[:, 7]))
+        self.co2_bc = co2
         self.sys.set_bcs(*pore_dirichlet(self.pp, self.bnd, co2))
         self.history.append(vals)
         self.CO2_min = float(np.amin(vals[:, 4]))
