@@ -1,0 +1,20 @@
+"""Extra golden cases: name -> (driver, keyword arguments of the reference CLI, number of time steps).
+
+Shared by tools/make_golden.py (which runs the CPU oracle and writes tests/golden/<name>_steps.npz) and by the GPU
+parity tests.  They walk the flag surface of the two scripts: bulk concentration file, published/intended weak form,
+voltage, pore length, cation (hydration numbers 1D:106-115), the PNP model (no steric term), the proton-flux controller
+(--H_OHP) and the H2 Faradaic efficiency."""
+
+EXTRA_PORE = {
+    "pore10_pub_v25": (dict(concentration_elec=0.5, L=10e-9, R=5e-9, voltage_multiplier=-2.5, as_published=True), 3),
+    "pore10_1M": (dict(concentration_elec=1.0, L=10e-9, R=5e-9), 2),
+    "pore25_fe": (dict(concentration_elec=0.5, L=25e-9, R=5e-9, H2_FE=0.2, current_rough=1000.0), 2),
+}
+
+EXTRA_EDL = {
+    "edl1_pnp": (dict(L_n=1e-6, model="PNP", voltage_multiplier=-2.5), 4),
+    "edl1_li": (dict(L_n=1e-6, cation="Li", voltage_multiplier=-2.5), 3),
+    "edl5_na": (dict(L_n=5e-6, cation="Na", voltage_multiplier=-2.5), 3),
+    "edl50_default": (dict(), 3),
+    "edl10_hohp": (dict(L_n=10e-6, voltage_multiplier=-2.5, H_OHP=0.5, H2_FE=0.4), 4),
+}

@@ -15,6 +15,7 @@ import scipy.sparse.linalg as spla
 
 import gmpnp_oracle as O
 from conftest import GOLDEN, random_state
+from golden_cases import EXTRA_EDL, EXTRA_PORE
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +198,39 @@ def test_pore_time_loop_matches_golden(case, nsteps, gpu_lib):
         co2 = run.problem.bc_vals[np.searchsorted(run.problem.bc_dofs, run.bnd.dirichlet_vertices[1][0] * 9 + 4)]
         assert abs(co2 - g["co2_bc"][nsteps - 1]) / co2 < 1e-9
         assert run.history[0][:, :8].min() == 1.0 and not run.history[0][:, 8].any()
+    finally:
+        run.sys.close()
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA_PORE))
+def test_pore_flag_surface_matches_golden(case, gpu_lib):
+    """Other corners of the 3D CLI (bulk file, published form at a higher voltage, pore length, H2_FE / current)."""
+    from gmpnp_amd.pore3d import PoreRun
+    kw, nsteps = EXTRA_PORE[case]
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    run = PoreRun(num_steps=nsteps, **kw)
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        for k in range(nsteps):
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
+        assert abs(run.co2_bc - g["co2_bc"][nsteps - 1]) / run.co2_bc < 1e-9
+    finally:
+        run.sys.close()
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA_EDL))
+def test_edl_flag_surface_matches_golden(case, gpu_lib):
+    """Other corners of the 1D CLI (PNP model, Li / Na hydration numbers, mesh length, the H_OHP flux controller)."""
+    from gmpnp_amd.edl1d import EDLRun
+    kw, nsteps = EXTRA_EDL[case]
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    run = EDLRun(num_steps=nsteps, **kw)
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        for k in range(nsteps):
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
     finally:
         run.sys.close()
 

@@ -166,3 +166,21 @@ def test_project_gradient_of_linear_field(pore10):
     f = 2.0 * mesh.coords[:, 0] - 3.0 * mesh.coords[:, 2]
     gproj = O.project_gradient(mesh.coords, mesh.cells, f, sign=-1.0)
     assert np.allclose(gproj, np.array([-2.0, 0.0, 3.0])[None, :], atol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["edl1_pnp", "edl1_li", "edl5_na", "edl10_hohp"])
+def test_oracle_reproduces_extra_edl_goldens(case):
+    """The committed flag-surface goldens are what the oracle gives today (guards against silent oracle edits)."""
+    import os
+    from conftest import GOLDEN
+    from golden_cases import EXTRA_EDL
+    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+    from gmpnp_amd.params import edl_parameters, utilities_dir
+    from gmpnp_amd.problem import edl_problem
+    kw, nsteps = EXTRA_EDL[case]
+    ep = edl_parameters(**kw)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
+    out = O.edl_time_loop(ep, edl_problem(ep, mesh), nsteps)
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    assert out["newton_its"] == list(g["newton_its"])
+    assert np.allclose(out["states"], g["states"], rtol=1e-9, atol=1e-12)

@@ -22,7 +22,9 @@ from gmpnp_amd.model import default_quadrature
 
 G = os.path.join(ROOT, "tests", "golden")
 os.makedirs(G, exist_ok=True)
-what = set(sys.argv[1:]) or {"elements", "pore10", "pore50", "edl1", "edl50"}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_cases import EXTRA_PORE, EXTRA_EDL
+what = set(sys.argv[1:]) or ({"elements", "pore10", "pore50", "edl1", "edl50"} | set(EXTRA_PORE) | set(EXTRA_EDL))
 
 
 def pad_res(res):
@@ -58,6 +60,30 @@ for key, (L, R, steps) in {"pore10": (10e-9, 5e-9, 3), "pore50": (50e-9, 5e-9, 2
 
 for key, kw, steps in (("edl1", dict(L_n=1e-6, cation="Cs", voltage_multiplier=-5.0), 5),
                        ("edl50", dict(cation="Cs", voltage_multiplier=-10.0), 3)):
+    if key not in what:
+        continue
+    t = time.time()
+    ep = edl_parameters(**kw)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
+    prob = edl_problem(ep, mesh)
+    out = O.edl_time_loop(ep, prob, steps, verbose=True)
+    np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
+                        residuals=pad_res(out["residuals"]))
+    print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
+
+for key, (kw, steps) in EXTRA_PORE.items():
+    if key not in what:
+        continue
+    t = time.time()
+    pp = pore_parameters(**kw)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    prob, bnd = pore_problem(pp, mesh)
+    out = O.pore_time_loop(pp, prob, bnd, steps, verbose=True)
+    np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
+                        residuals=pad_res(out["residuals"]), co2_bc=np.array(out["co2_bc"]))
+    print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
+
+for key, (kw, steps) in EXTRA_EDL.items():
     if key not in what:
         continue
     t = time.time()
