@@ -80,13 +80,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # rehearsal on a one-GPU box: GMPNP_BENCH_BACKEND=gloo lets several ranks share the card (ranks map onto the visible
+    # devices modulo their count); the driver's runs use RCCL ("nccl") with one rank per GPU
+    backend = os.environ.get("GMPNP_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     if a.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -130,9 +138,9 @@ def main():
     its = float(sum(run.newton_its))
     kry = float(run.sys.krylov_iterations)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s = torch.tensor([its, kry], dtype=torch.float64, device="cuda")
+        s = torch.tensor([its, kry], dtype=torch.float64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         dt, its, kry = float(t[0]), float(s[0]), float(s[1])
 
