@@ -78,10 +78,22 @@ template <int DIM, int NF, bool WANT_J>
 __global__ __launch_bounds__(64) void k_element(const Ctx c) {
   using L = Lay<DIM, NF>;
   constexpr int NS = L::NS, NN = L::NN;
+  // Coefficient and quadrature tables go to LDS first: read through the global pointers they would be re-fetched with
+  // a vector load (and a full wait) at every use, because the element stores below may alias them.
+  __shared__ gmpnp_model_t m;
+  __shared__ gmpnp_quadrature_t qd;
+  {
+    static_assert(sizeof(gmpnp_model_t) % 4 == 0 && sizeof(gmpnp_quadrature_t) % 4 == 0, "word-wise staging");
+    const uint32_t* gm = reinterpret_cast<const uint32_t*>(c.model);
+    const uint32_t* gq = reinterpret_cast<const uint32_t*>(c.quad);
+    uint32_t* lm = reinterpret_cast<uint32_t*>(&m);
+    uint32_t* lq = reinterpret_cast<uint32_t*>(&qd);
+    for (int w = threadIdx.x; w < (int)(sizeof(gmpnp_model_t) / 4); w += blockDim.x) lm[w] = gm[w];
+    for (int w = threadIdx.x; w < (int)(sizeof(gmpnp_quadrature_t) / 4); w += blockDim.x) lq[w] = gq[w];
+  }
+  __syncthreads();
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= c.nc) return;
-  const gmpnp_model_t& m = *c.model;
-  const gmpnp_quadrature_t& qd = *c.quad;
 
   int nd[NN];
   double X[NN][DIM], U[NN][NF];
