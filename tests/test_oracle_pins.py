@@ -98,3 +98,18 @@ def test_full_model_eps_ohp_near_recorded_values(k_problem):
         u0 = sol[V][0]
         eps = prob.model.eps0 + prob.model.epsc @ u0[:6]
         assert abs(eps - RECORDED[V]) / RECORDED[V] < 3e-3
+
+
+def test_oracle_field_ohp_near_recorded_value():
+    """The recorded OHP field of reference 1D/Stern_CO2ER.py:67 (V = -2.5: -0.0803 V/nm) with the ORACLE: the 1D
+    defaults (K+, 0.1 M, MPNP, 50 um mesh), 40 time steps, consistent-mass projection of -grad(p) (1D:802-805), value at
+    the x = 0 vertex rescaled as in 1D:893-897.  After 40 steps the field is at 98.4 % of the recorded value and still
+    rising (the GPU test runs the same case for 300 steps and lands within 0.6 %)."""
+    ep = edl_parameters(voltage_multiplier=-2.5)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
+    out = O.edl_time_loop(ep, edl_problem(ep, mesh), 40)
+    p = out["states"][-1].reshape(mesh.num_vertices, 7)[:, 6]
+    fld = O.project_gradient(mesh.coords, mesh.cells, p, sign=-1.0)[:, 0]
+    field_ohp = fld[int(np.argmin(mesh.coords[:, 0]))] * ep.thermal_voltage / ep.L_n * 1e-9
+    assert abs(field_ohp / -0.08032108300135771 - 1.0) < 0.025
+    assert field_ohp > -0.08032108300135771  # approaching from below in magnitude
