@@ -69,7 +69,7 @@ struct gmpnp_solver {
   // device storage
   DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
   DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, vals_s, Dinv, AP, AcPart, Ac, Aci;
-  DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, kb, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
+  DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, kxp, kb, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
       part_a, part_b, part_f;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
       slice_node0, slice_nn, node_slice, sell_cols, sell_blk, wl_slice, wl_kpos, tile_slice0, tile_agg, tile_slot,
@@ -87,6 +87,10 @@ struct gmpnp_solver {
   bool jacobian_valid = false, precond_valid = false;
   int precond_mode = -1;
   int precond_lag = 1;  // rebuild Dinv / coarse inverse every precond_lag-th Newton iteration of a solve
+  bool state_jumped = true;     // u was set from outside since the last Newton solve: the Jacobian moves a lot, no coarse reuse
+  bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
+  int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
+  int warm_start = 2;  // start Newton iteration k+1's linear solve from (1 - omega) dx_k (GMPNP_WARM_START=0 disables)
   int coarse_lag = 3;   // rebuild the coarse inverse alone every coarse_lag-th Newton iteration of a solve (measured best: 1 -> 3 costs 0.7 % more Krylov iterations and saves 155 us per skipped rebuild)
   // SpMV event sampling (eager mode)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
@@ -380,29 +384,54 @@ int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double
 // formed with the unscaled matrix; if it misses the target grossly (> 1000x), the solve restarts on it (dx accumulates
 // in kx).  stats->residual_norm reports the TRUE residual.
 // rhs in c.kr on entry; dx = kx on return.
+// kr = kb - J kx with the unscaled matrix; returns ||kr|| (synchronises the stream)
+template <int NF>
+int true_residual(gmpnp_solver* s, double* rn) {
+  hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+  hipLaunchKernelGGL(k_true_residual, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kb.p, (const double*)s->kt.p,
+                     s->kr.p, s->part_f.p, (int)s->ndof);
+  HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double acc = 0.0;
+  for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
+  *rn = std::sqrt(acc);
+  return GMPNP_OK;
+}
+
+// `warm_scale` != 0: kx holds the previous Newton correction; the solve starts from x0 = warm_scale * kx, i.e. BiCGStab
+// only has to remove b - J x0.  With the reference's damped update (omega = 0.9) consecutive corrections satisfy
+// dx_{k+1} = (1 - omega) dx_k + O(|dx_k|^2), so x0 = (1 - omega) dx_k leaves a second-order small residual and the
+// same absolute target is reached in far fewer iterations.  Falls back to x0 = 0 when x0 does not reduce the residual.
 template <int NF>
 int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st,
-                    int verify_above = 0) {
+                    int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0) {
   const int n = s->ndof;
   const double tol = std::max(rtol * bnorm, atol);
   HIP_TRY(hipMemcpyAsync(s->kb.p, s->kr.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   gmpnp_linear_stats_t total{}; total.rhs_norm = bnorm;
   double rhs_norm = bnorm;
+  bool warm = false;
+  if (warm_scale != 0.0 && bnorm > 0.0) {
+    hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
+    double rn = 0.0;
+    int rc = true_residual<NF>(s, &rn); if (rc) return rc;  // kr = b - J x0
+    if (rn == rn && rn < 0.5 * bnorm) { warm = true; rhs_norm = rn; }
+    else HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  }
   for (int pass = 0;; ++pass) {
     gmpnp_linear_stats_t ls{};
-    int rc = pass == 0 ? krylov<NF>(s, mode, rhs_norm, rtol, atol, maxit, &ls) : krylov<NF>(s, mode, rhs_norm, 0.0, tol, maxit, &ls, true);
+    int rc;
+    if (pass == 0 && !warm) rc = krylov<NF>(s, mode, rhs_norm, rtol, atol, maxit, &ls);
+    else if (rhs_norm <= tol) { ls.converged = 1; ls.residual_norm = rhs_norm; rc = GMPNP_OK; }  // x0 is already good enough
+    else rc = krylov<NF>(s, mode, rhs_norm, 0.0, tol, maxit, &ls, pass > 0);
     total.iterations += ls.iterations; total.converged = ls.converged; total.residual_norm = ls.residual_norm;
     if (rc) { if (st) *st = total; return rc; }
-    rc = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, pass == 0 ? 0.0 : 1.0, 1.0); if (rc) return rc;
+    if (ls.iterations > 0 || (pass == 0 && !warm)) {
+      rc = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, (pass == 0 && !warm) ? 0.0 : 1.0, 1.0); if (rc) return rc;
+    }
     if (!(bnorm > 0.0) || (pass == 0 && ls.iterations <= verify_above)) break;  // short solves do not drift
-    hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
-    hipLaunchKernelGGL(k_true_residual, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kb.p, (const double*)s->kt.p,
-                       s->kr.p, s->part_f.p, n);
-    HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    double acc = 0.0;
-    for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
-    const double rn = std::sqrt(acc);
+    double rn = 0.0;
+    rc = true_residual<NF>(s, &rn); if (rc) return rc;
     total.residual_norm = rn;
     // Within 1000x of the target: accepted.  A 1e-10 solve of a small right-hand side ends at the attainable accuracy of
     // b - J dx in fp64 (3-30x the target late in a run) and a restart cannot improve that; the check is there for gross
@@ -514,16 +543,27 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
         return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh");
       }
     } else {
+      // The coarse inverse is reused for up to coarse_lag Newton iterations, unless the state was just set from outside
+      // (first solve of a run: the Jacobian changes a lot between iterations) or the last reuse cost iterations.
+      const bool coarse_fresh = s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || s->state_jumped || s->coarse_refresh_due;
       rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, s->precond_lag <= 1 || (st.iterations % s->precond_lag) == 0,
-                                         s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0); if (rc) return rc;
+                                         coarse_fresh); if (rc) return rc;
       // rhs = b (current residual vector F)
       HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
       HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       gmpnp_linear_stats_t ls{};
       // inside Newton only long solves are checked: a short one does not drift, and Newton's own residual test sees
       // whatever is left
+      // x0 = (1-w) dx_k + (1-w)^2 (dx_k - (1-w) dx_{k-1}): first-order prediction plus the second-order term observed
+      // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (GMPNP_WARM_START=1: first order only)
+      const double q = 1.0 - o.relaxation_parameter;
+      double wa = 0.0, wb = 0.0;
+      if (s->warm_start && st.iterations > 0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
-                               o.krylov_maximum_iterations, &ls, 500);
+                               o.krylov_maximum_iterations, &ls, 500, wa, wb);
+      // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
+      if (coarse_fresh) { s->krylov_fresh_iters = ls.iterations; s->coarse_refresh_due = false; }
+      else if (ls.iterations > 2 * s->krylov_fresh_iters + 10) s->coarse_refresh_due = true;
       if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
       st.krylov_iterations += ls.iterations;
       if (rc) {
@@ -555,6 +595,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
     done = conv(r);
   }
+  s->state_jumped = false;
   st.converged = done ? 1 : 0;
   st.ms_total = now_ms() - t0;
   if (!done) return fail(GMPNP_ERR_NOT_CONVERGED, "Newton solver did not converge because maximum number of iterations reached");
@@ -668,7 +709,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
-  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kb}) HIP_TRY(b->alloc(ndof));
+  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb}) HIP_TRY(b->alloc(ndof));
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
@@ -681,6 +722,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   if (const char* gi = std::getenv("GMPNP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::atoi(gi));
   if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_COARSE_LAG")) s->coarse_lag = std::max(1, std::atoi(pl));
+  if (const char* pl = std::getenv("GMPNP_WARM_START")) s->warm_start = std::atoi(pl);
   HIP_TRY(hipHostMalloc((void**)&s->h_part, std::max(s->n_resblocks, 1) * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
 
@@ -753,7 +795,7 @@ int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const d
 int gmpnp_set_state(gmpnp_solver* s, const double* u, const double* u_n) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (u) { int rc = upload_vec(s, u, s->u.p); if (rc) return rc; }
+  if (u) { int rc = upload_vec(s, u, s->u.p); if (rc) return rc; s->state_jumped = true; }
   if (u_n) { int rc = upload_vec(s, u_n, s->un.p); if (rc) return rc; }
   s->jacobian_valid = false;
   return GMPNP_OK;

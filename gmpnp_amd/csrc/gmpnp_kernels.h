@@ -1361,6 +1361,17 @@ __global__ __launch_bounds__(kVecBlock) void k_true_residual(const double* __res
   if (threadIdx.x == 0) part[blockIdx.x] = w[0];
 }
 
+__global__ void k_scale(double* __restrict__ x, double a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= a;
+}
+
+// warm start of the next Newton correction: x <- a x + b xp, xp <- old x  (x = dx_k, xp = dx_{k-1})
+__global__ void k_warm_start(double* __restrict__ x, double* __restrict__ xp, double a, double b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double t = x[i]; x[i] = a * t + (b != 0.0 ? b * xp[i] : 0.0); xp[i] = t; }
+}
+
 __global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, double a, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += a * x[i];
