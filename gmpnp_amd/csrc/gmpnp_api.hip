@@ -423,8 +423,20 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     int rc;
     if (pass == 0 && !warm) rc = krylov<NF>(s, mode, rhs_norm, rtol, atol, maxit, &ls);
     else if (rhs_norm <= tol) { ls.converged = 1; ls.residual_norm = rhs_norm; rc = GMPNP_OK; }  // x0 is already good enough
-    else rc = krylov<NF>(s, mode, rhs_norm, 0.0, tol, maxit, &ls, pass > 0);
+    else {
+      // a warm-started solve that needs more than 3x the previous solve's iterations is abandoned (cold repeat below)
+      const int uc = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+      const int cap = (pass == 0 && warm) ? std::min(maxit, 3 * std::max(60, s->last_krylov_iters[uc])) : maxit;
+      rc = krylov<NF>(s, mode, rhs_norm, 0.0, tol, cap, &ls, pass > 0);
+    }
     total.iterations += ls.iterations; total.converged = ls.converged; total.residual_norm = ls.residual_norm;
+    if (rc == GMPNP_ERR_LINEAR && pass == 0 && warm) {
+      // BiCGStab can stagnate on one right-hand side and not on another: a failed warm-started solve is repeated cold
+      warm = false; rhs_norm = bnorm; pass = -1;
+      HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+      continue;
+    }
     if (rc) { if (st) *st = total; return rc; }
     if (ls.iterations > 0 || (pass == 0 && !warm)) {
       rc = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, (pass == 0 && !warm) ? 0.0 : 1.0, 1.0); if (rc) return rc;
