@@ -17,8 +17,9 @@ tested at world_size 2) but cannot beat one GPU on a 3.7k-vertex mesh (DESIGN.md
 bench times.
 
 Extra objects on the JSON line:
-  roofline      dominant kernels = the two fused BiCGStab half-iterations k_bicg_a / k_bicg_b (one SELL block SpMV each plus
-                the vector updates).  achieved = algorithmic bytes of ONE SpMV (648 nb + 4 nb + 4 (nv+1) +
+  roofline      dominant kernels = the two fused BiCGStab half-iterations (k_half_a / k_half_b on meshes whose workgroups are
+                all resident at once, else k_bicg_a / k_bicg_b after a separate coarse launch): one SELL block SpMV each
+                plus the vector updates.  achieved = algorithmic bytes of ONE SpMV (648 nb + 4 nb + 4 (nv+1) +
                 16 nd; the vector traffic fused in is not counted) / mean kernel duration, sampled LIVE during the timed
                 region: every 32nd launch carries a start/stop HIP event pair attached to the dispatch itself
                 (hipExtLaunchKernelGGL on the solver's stream), i.e. the kernel's own begin-to-end time.
@@ -151,6 +152,13 @@ def main():
         nf = dev.nf
         alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
         mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(4, 200)
+        launches = dev.krylov_launches_per_iteration
+        if launches == 2:
+            kernel_name = ("k_half_a / k_half_b (one launch per BiCGStab half-iteration: the coarse workgroups ride in front of "
+                           "the tile workgroups = SELL node-block SpMV + vector updates, fp64; the launch duration includes "
+                           "the in-launch wait for the coarse result, which the 4-launch form spends in a separate launch)")
+        else:
+            kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")
@@ -170,11 +178,11 @@ def main():
                        "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,
                        "krylov_iterations": kry,
                        "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV "
-                                                   "+ vector updates, fp64)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
-                         "launches_sampled": prof["sampled"], "launches_total": prof["launched"]},
+                         "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
+                         "launches_per_krylov_iteration": launches},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(run)

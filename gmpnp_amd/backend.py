@@ -26,7 +26,7 @@ EXPORTS = [
     "gmpnp_version", "gmpnp_last_error", "gmpnp_create", "gmpnp_destroy", "gmpnp_set_model",
     "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
-    "gmpnp_n_aggregates", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
+    "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
 ]
 
@@ -101,6 +101,8 @@ def load_library(path: str = None):
         getattr(lib, name).restype = c_int64
     lib.gmpnp_n_aggregates.argtypes = [c_void_p]
     lib.gmpnp_n_aggregates.restype = c_int32
+    lib.gmpnp_krylov_launches_per_iteration.argtypes = [c_void_p]
+    lib.gmpnp_krylov_launches_per_iteration.restype = c_int32
     lib.gmpnp_assemble.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_get_jacobian_csr.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_double)]
     lib.gmpnp_spmv.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
@@ -251,6 +253,10 @@ class DeviceSolver:
     @property
     def n_aggregates(self):
         return int(self.lib.gmpnp_n_aggregates(self._h))
+
+    @property
+    def krylov_launches_per_iteration(self):
+        return int(self.lib.gmpnp_krylov_launches_per_iteration(self._h))
 
     def set_model(self, model: Model):
         cm = to_cmodel(model)

@@ -90,6 +90,9 @@ struct gmpnp_solver {
   bool state_jumped = true;     // u was set from outside since the last Newton solve: the Jacobian moves a lot, no coarse reuse
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
   int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
+  DevBuf<uint32_t> ticket;
+  bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); GMPNP_FUSED_HALF=1
+  unsigned fused_seq = 0;   // fused launches so far in the current solve
   int warm_start = 2;  // start Newton iteration k+1's linear solve from (1 - omega) dx_k (GMPNP_WARM_START=0 disables)
   int coarse_lag = 3;   // rebuild the coarse inverse alone every coarse_lag-th Newton iteration of a solve (measured best: 1 -> 3 costs 0.7 % more Krylov iterations and saves 155 us per skipped rebuild)
   // SpMV event sampling (eager mode)
@@ -272,7 +275,17 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
   const dim3 cg(std::max(1, s->t.nagg));
   // sampled launches attach the events to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the kernel's
   // own begin-to-end time, the quantity rocprofv3's kernel trace reports
-  if (WHICH == 0) {
+  if (s->fused_half) {
+    const dim3 fg(s->t.nagg + s->t.ntiles);
+    const unsigned target = (unsigned)s->t.nagg * (++s->fused_seq);
+    if (WHICH == 0) {
+      if (ev) hipExtLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
+      else hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
+    } else {
+      if (ev) hipExtLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
+      else hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
+    }
+  } else if (WHICH == 0) {
     hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
     if (ev) hipExtLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
     else hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
@@ -314,6 +327,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   const int n = s->ndof;
   hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr, s->kr.p, n);
   HIP_TRY(hipMemsetAsync(s->ky.p, 0, n * sizeof(double), s->stream));
+  if (s->fused_half) { HIP_TRY(hipMemsetAsync(s->ticket.p, 0, 16 * 66 * sizeof(uint32_t), s->stream)); s->fused_seq = 0; }
   if (use_coarse)  // P^T b partials where A(0) expects them
     hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->kr.p, s->cpart_v1.p);
   KrylovScalars init{};
@@ -519,6 +533,7 @@ std::string status_message(int flags) {
   if (flags & 1) m += "1 - sum_j a_j u_j <= 0 at a quadrature point; ";
   if (flags & 2) m += "singular diagonal node block; ";
   if (flags & 4) m += "singular coarse operator; ";
+  if (flags & 8) m += "in-launch hand-over timed out; ";
   return m;
 }
 
@@ -602,7 +617,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     st.ms_setup += ms12;
     st.ms_krylov += ms23;
     if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
-    if (flags & 6) return fail(GMPNP_ERR_LINEAR, status_message(flags));
+    if (flags & 14) return fail(GMPNP_ERR_LINEAR, status_message(flags));
     if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
     if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
     done = conv(r);
@@ -725,6 +740,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
+  HIP_TRY(s->ticket.alloc(16 * 66));  // counter + 64 replicated flags, one cache line each
   HIP_TRY(s->part_a.alloc((size_t)2 * t.ntiles));  // (rhat,v) partials, then ||r||^2 partials
   HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
   HIP_TRY(s->part_f.alloc(s->n_resblocks));
@@ -735,6 +751,13 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_COARSE_LAG")) s->coarse_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_WARM_START")) s->warm_start = std::atoi(pl);
+  {  // fused launch form only where every workgroup of a launch is resident at once (3 x 512 threads per CU): there the
+     // hand-over inside the launch beats a launch boundary (+5 % on L_50_R_5); with more tiles than slots it loses (-4 %)
+    hipDeviceProp_t prop{};
+    HIP_TRY(hipGetDeviceProperties(&prop, s->opts.device_id));
+    s->fused_half = mesh->dim == 3 && (s->t.ntiles + s->t.nagg) <= 3 * prop.multiProcessorCount;
+  }
+  if (const char* pl = std::getenv("GMPNP_FUSED_HALF")) s->fused_half = std::atoi(pl) != 0;
   HIP_TRY(hipHostMalloc((void**)&s->h_part, std::max(s->n_resblocks, 1) * sizeof(double)));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
 
@@ -757,7 +780,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.yc = s->yc.p;
   c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
   c.cpart_v[0] = s->cpart_v0.p; c.cpart_v[1] = s->cpart_v1.p; c.cpart_t = s->cpart_t.p;
-  c.part_a = s->part_a.p; c.part_rr = s->part_a.p + t.ntiles; c.part_b = s->part_b.p;
+  c.ticket = s->ticket.p; c.part_a = s->part_a.p; c.part_rr = s->part_a.p + t.ntiles; c.part_b = s->part_b.p;
   c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;
@@ -847,6 +870,7 @@ int64_t gmpnp_n_dofs(const gmpnp_solver* s) { return s ? s->ndof : 0; }
 int64_t gmpnp_n_blocks(const gmpnp_solver* s) { return s ? s->nb : 0; }
 int64_t gmpnp_jacobian_nnz(const gmpnp_solver* s) { return s ? (int64_t)s->nb * s->nf * s->nf : 0; }
 int32_t gmpnp_n_aggregates(const gmpnp_solver* s) { return s ? s->t.nagg : 0; }
+int32_t gmpnp_krylov_launches_per_iteration(const gmpnp_solver* s) { return s ? (s->fused_half ? 2 : 4) : 0; }
 
 int gmpnp_assemble(gmpnp_solver* s, int32_t want_jacobian, double* F_out, double* norm_out) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
@@ -923,7 +947,7 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
     rc = tri_apply<7>(s, s->kx.p, 0.0, 1.0); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
+    if (*s->h_status & 14) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
     if (stats) { stats->iterations = 1; stats->converged = 1; stats->residual_norm = 0.0; stats->rhs_norm = bn; }
     return download_vec(s, s->kx.p, x);
   }
@@ -933,7 +957,7 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   GMPNP_DISPATCH(s, rc = (krylov_verified<NF>(s, mode, bn, rtol, atol, maxit, &ls)));
   if (stats) *stats = ls;
   HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (*s->h_status & 6) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
+  if (*s->h_status & 14) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
   if (rc) return rc;
   return download_vec(s, s->kx.p, x);
 }
@@ -951,7 +975,7 @@ int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* 
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (*s->h_status & 6) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
+    if (*s->h_status & 14) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
   }
   rc = upload_vec(s, r, s->ky.p); if (rc) return rc;
   GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));

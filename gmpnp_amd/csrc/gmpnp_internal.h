@@ -146,7 +146,8 @@ struct Ctx {
   double* part_b;   // [4][ntiles]   (t,s) (t,t) (rhat,s) (rhat,t) (B)
   double* part_f;   // residual-norm partials
   KrylovScalars* scal;
-  int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse)
+  int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse, bit 3: hand-over timeout)
+  uint32_t* ticket; // fused launch form: coarse workgroups finished so far in this solve
 };
 
 // Host-side topology/layout tables (internal vertex order).

@@ -772,12 +772,20 @@ struct TileCoarse {
   static_assert(ROWS * 8 <= kKrylovThreads, "one pass: 8 lanes per coarse dof of the tile");
   double a0, a1;
   int d;
-  __device__ inline void load(const Ctx& c, int tile) {  // straight-line: requests only
-    const int t = threadIdx.x, n = c.ncoarse, l = t & 7, rc = min(t >> 3, ROWS - 1);
+  __device__ inline void load_index(const Ctx& c, int tile) {  // straight-line: requests only
+    const int t = threadIdx.x, rc = min(t >> 3, ROWS - 1);
     const int ag = c.tile_aggs[tile * kTileAggs + rc / NF];
     d = ag * NF + (rc - (rc / NF) * NF);
-    a0 = c.yc[(size_t)min(l, c.nagg - 1) * n + d];
-    a1 = c.yc[(size_t)min(l + 8, c.nagg - 1) * n + d];
+  }
+  template <bool COHERENT>
+  __device__ inline void load_values(const Ctx& c) {
+    const int n = c.ncoarse, l = threadIdx.x & 7;
+    const double* p0 = c.yc + (size_t)min(l, c.nagg - 1) * n + d;
+    const double* p1 = c.yc + (size_t)min(l + 8, c.nagg - 1) * n + d;
+    if (COHERENT) {  // written by coarse workgroups of the same launch: agent-scope loads, no cached copy
+      a0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { a0 = *p0; a1 = *p1; }
   }
   // ycl[kMaxCoarse], indexed by the global coarse dof; the caller synchronises
   __device__ inline void to_lds(const Ctx& c, double* ycl) {
@@ -881,18 +889,70 @@ constexpr int kStagePre = 2;  // staged x entries per thread requested up front 
 // Early exit of a finished solve.  The requested values get a (never executed) use on the exit path: without it the
 // compiler sinks every request below this branch, i.e. behind the scalar round trip that fetches the flag.
 #define GMPNP_EXIT_IF_DONE(flag, keep_expr) do { if (flag) { if (c.ndof < 0) c.yc[0] = (keep_expr); return; } } while (0)
+// ---- in-launch hand-over from the coarse workgroups to the tile workgroups (fused launch form) ---------------------
+constexpr int kFlagCopies = 64;  // the "all coarse workgroups done" flag is replicated over 64 cache lines: 8 pollers per line
+template <bool FUSED>
+__device__ __forceinline__ void publish_ticket(const Ctx& c, unsigned target) {
+  if (FUSED) {
+    // No fences: the payload (yc, scalars) went out as agent-scope write-through stores (store_coherent); every thread
+    // drains its own stores, then one thread advances the counter.  A release fence would write back the whole L2 of
+    // the XCD and the consumers' acquire would invalidate theirs 66 times per launch (measured: +7 us per launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(c.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == target);
+    __syncthreads();
+    // the last coarse workgroup raises the replicated flags (launch sequence number = target / nagg is monotone)
+    if (last && threadIdx.x < kFlagCopies)
+      __hip_atomic_store(c.ticket + 16 * (1 + threadIdx.x), target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned target, int tile) {
+  __shared__ int ticket_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned* flag = c.ticket + 16 * (1 + (tile & (kFlagCopies - 1)));
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (wall_clock64() - t0 > 500000ull) {  // 5 ms at 100 MHz: never in a healthy run; ends the solve (later launches exit at once)
+        ok = 0; atomicOr(c.status, 8); c.scal->done = 3; break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ticket_ok = ok;
+  }
+  __syncthreads();
+  return ticket_ok != 0;
+}
+// scalar written by another workgroup of the SAME launch: a vector load at agent scope (a scalar load could hit a stale
+// line of the scalar cache, which earlier reads of the same struct pulled in)
+__device__ __forceinline__ double load_coherent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool FUSED>
+__device__ __forceinline__ void store_coherent(double* p, double v) {
+  if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool FUSED>
+__device__ __forceinline__ void store_coherent(int32_t* p, int32_t v) {
+  if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ double load_coherent(const int32_t* p) {
+  return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- coarse kernels: scalars of the half-iteration, yc = Aci * (P^T p  or  P^T s) in column blocks ----------------
 // One workgroup per aggregate g.  It sums the per-tile restriction partials of ITS NF coarse dofs only (fixed order),
 // forms the NF entries of the coarse operand and writes the column-block product yc[g][:] = Aci[:, g-block] * operand_g;
 // the tile kernels add the nagg blocks for the few coarse dofs they prolong from (TileCoarse).  Every workgroup
 // reduces the scalar partials redundantly; workgroup 0 publishes the scalars.
-template <int NF>
-__global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const int k) {
+template <int NF, bool FUSED>
+__device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const int g, const unsigned target) {
   __shared__ double cs[4 * NF];
   __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 4];
   KrylovScalars* sc = c.scal;
-  const int t = threadIdx.x, n = c.ncoarse, g = blockIdx.x;
+  const int t = threadIdx.x, n = c.ncoarse;
   const int par = k & 1;  // the iteration index comes from the host: no load stands in front of the requests below
   const bool first = (k == 0);
   // all requests first (the `done` flag among them: a finished solve still issues them, then exits)
@@ -936,8 +996,8 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const 
     __syncthreads();
   }
   GMPNP_STAMP(3);
-  if (g == 0 && t == 0) { sc->omega = omega; sc->beta = beta; sc->rho[par] = rho_new; }
-  if (!c.use_coarse) return;
+  if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->omega, omega); store_coherent<FUSED>(&sc->beta, beta); sc->rho[par] = rho_new; }
+  if (!c.use_coarse) { publish_ticket<FUSED>(c, target); return; }
   if (t < NF) {
     const double vc = cs[t];
     double rcn, pcn;
@@ -951,21 +1011,23 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const 
   }
   __syncthreads();
   GMPNP_STAMP(4);
-  if (t >= n) return;
-  double acc = 0.0;
+  if (t < n) {
+    double acc = 0.0;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
-  c.yc[(size_t)g * n + t] = acc;
+    for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
+    store_coherent<FUSED>(&c.yc[(size_t)g * n + t], acc);
+  }
+  publish_ticket<FUSED>(c, target);
   GMPNP_STAMP(5);
 }
 
-template <int NF>
-__global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) {
+template <int NF, bool FUSED>
+__device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const int g, const unsigned target) {
   __shared__ double cs[2 * NF];
   __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 2];
   KrylovScalars* sc = c.scal;
-  const int t = threadIdx.x, n = c.ncoarse, g = blockIdx.x;
+  const int t = threadIdx.x, n = c.ncoarse;
   const int par = k & 1;
   const int done_flag = sc->done, max_iters = sc->max_iters;
   const double rho_new = sc->rho[par], tol = sc->tol;
@@ -994,20 +1056,22 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const 
   else if (rv == 0.0 || rho_new == 0.0) done = 3;
   // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
   const double alpha = done ? 0.0 : rho_new / rv;
-  if (g == 0 && t == 0) { sc->alpha = alpha; sc->rr = rr; sc->done_next = done; }
-  if (done || !c.use_coarse) return;
+  if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->alpha, alpha); sc->rr = rr; store_coherent<FUSED>(&sc->done_next, (int32_t)done); }
+  if (done || !c.use_coarse) { publish_ticket<FUSED>(c, target); return; }
   if (t < NF) pcs[t] = cs[NF + t] - alpha * cs[t];  // P^T s = P^T r_k - alpha P^T v_k
   __syncthreads();
-  if (t >= n) return;
-  double acc = 0.0;
+  if (t < n) {
+    double acc = 0.0;
 #pragma unroll
-  for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
-  c.yc[(size_t)g * n + t] = acc;
+    for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
+    store_coherent<FUSED>(&c.yc[(size_t)g * n + t], acc);
+  }
+  publish_ticket<FUSED>(c, target);
 }
 
 // ---- fused half-iterations ------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) {
+template <int NF, bool FUSED>
+__device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int tile, const unsigned target) {
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
@@ -1017,13 +1081,15 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   __shared__ double own[6][64];
   static_assert(kSlicesPerTile == 1 && NW >= 6, "own-row hand-over: one slice per tile, one wave per vector");
   KrylovScalars* sc = c.scal;
-  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int sl = wv / NW;
   const int par = k & 1, n = c.ncoarse;
   const bool first = (k == 0);
   GMPNP_STAMP(0);
   const int done_flag = sc->done;
-  const double alpha = sc->alpha, omega = sc->omega, beta = sc->beta;
+  const double alpha = sc->alpha;
+  double omega = 0.0, beta = 0.0;
+  if (!FUSED) { omega = sc->omega; beta = sc->beta; }
   const double* __restrict__ po = c.kp[par ^ 1];
   const double* __restrict__ vo = c.kv[par ^ 1];
   const double* __restrict__ sfirst = first ? c.kr : c.ks;  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
@@ -1039,7 +1105,8 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
     st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
   }
   TileCoarse<NF> tcs;
-  tcs.load(c, tile);
+  tcs.load_index(c, tile);
+  if (!FUSED) tcs.template load_values<false>(c);
   TileRows<NF> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
@@ -1055,12 +1122,17 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
   const int own_r = rows.row;  // inactive lanes: row 0
   const double* ownp = wv == 0 ? c.krhat : wv == 1 ? sfirst : wv == 2 ? c.kt : wv == 3 ? po : wv == 4 ? vo : c.ky;
   const double own_q = ownp[own_r];
-  { double keep = own_q + tcs.a0 + tcs.a1;
+  { double keep = own_q + (FUSED ? 0.0 : tcs.a0 + tcs.a1);
 #pragma unroll
     for (int u = 0; u < kStagePre; ++u) keep += (st_s[u] + st_t[u]) + (st_p[u] + st_v[u]);
 #pragma unroll
     for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
+  if (FUSED) {  // scalars and coarse products of THIS launch's coarse workgroups
+    if (!wait_ticket(c, target, tile)) return;
+    omega = load_coherent(&sc->omega); beta = load_coherent(&sc->beta);
+    tcs.template load_values<true>(c);
+  }
   GMPNP_STAMP(1);
   const bool uc = c.use_coarse != 0;
   if (uc) { tcs.to_lds(c, ycl); __syncthreads(); }
@@ -1126,8 +1198,8 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const in
 #endif
 }
 
-template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) {
+template <int NF, bool FUSED>
+__device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int tile, const unsigned target) {
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[kSlicesPerTile][64];
@@ -1136,11 +1208,13 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
   __shared__ double ycl[kMaxCoarse];
   __shared__ double own[3][64];
   KrylovScalars* sc = c.scal;
-  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int sl = wv / NW;
-  const int done_flag = sc->done, dn = sc->done_next;  // dn: verdict of k_coarse_b(k) on ||r_k||
+  const int done_flag = sc->done;
+  int dn = 0;  // verdict of k_coarse_b(k) on ||r_k||
   const int par = k & 1, n = c.ncoarse;
-  const double alpha = sc->alpha;
+  double alpha = 0.0;
+  if (!FUSED) { dn = sc->done_next; alpha = sc->alpha; }
   const double* __restrict__ vn = c.kv[par];
   const TileRec rec = c.tile_rec[tile];
   const int c0 = tile * c.col_stride;
@@ -1151,7 +1225,8 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
     st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
   }
   TileCoarse<NF> tcs;
-  tcs.load(c, tile);
+  tcs.load_index(c, tile);
+  if (!FUSED) tcs.template load_values<false>(c);
   TileRows<NF> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
@@ -1165,12 +1240,17 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
   const int own_r = rows.row;  // inactive lanes: row 0
   const double* ownp = wv == 0 ? c.krhat : wv == 1 ? c.kr : vn;  // wave q requests own-row vector q (see k_bicg_a)
   const double own_q = ownp[own_r];
-  { double keep = own_q + tcs.a0 + tcs.a1;
+  { double keep = own_q + (FUSED ? 0.0 : tcs.a0 + tcs.a1);
 #pragma unroll
     for (int u = 0; u < kStagePre; ++u) keep += st_r[u] + st_v[u];
 #pragma unroll
     for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
+  if (FUSED) {
+    if (!wait_ticket(c, target, tile)) return;
+    dn = (int)load_coherent(&sc->done_next); alpha = load_coherent(&sc->alpha);
+    if (!dn) tcs.template load_values<true>(c);
+  }
   if (dn) {
     if (tile == 0 && t == 0) sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
     return;
@@ -1220,6 +1300,34 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
     }
     if (tile == 0) sc->iters = k + 1;
   }
+}
+
+// ---- launch forms ---------------------------------------------------------------------------------------------
+// Four launches per iteration (coarse_a, bicg_a, coarse_b, bicg_b) ...
+template <int NF>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const int k) { coarse_a_body<NF, false>(c, k, blockIdx.x, 0u); }
+template <int NF>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) { coarse_b_body<NF, false>(c, k, blockIdx.x, 0u); }
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, blockIdx.x, 0u); }
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, blockIdx.x, 0u); }
+
+// ... or two: the nagg coarse workgroups ride in front of the tile workgroups of the same launch.  A tile workgroup
+// requests everything that does not depend on the coarse result (indices, matrix slice, operand vectors), then waits
+// for the ticket counter to reach `target` (= nagg x launches so far in this solve) before it reads the scalars and
+// the coarse products.  Coarse workgroups have the lowest block indices (dispatched first) and wait for nobody, so
+// the counter always arrives; the wait is bounded by a wall-clock budget all the same (status bit 8).
+static_assert(kCoarseThreads == kKrylovThreads, "coarse and tile workgroups share a launch");
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads, 6) void k_half_a(const Ctx c, const int k, const unsigned target) {
+  if ((int)blockIdx.x < c.nagg) coarse_a_body<NF, true>(c, k, blockIdx.x, target);
+  else bicg_a_body<NF, true>(c, k, blockIdx.x - c.nagg, target);
+}
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b(const Ctx c, const int k, const unsigned target) {
+  if ((int)blockIdx.x < c.nagg) coarse_b_body<NF, true>(c, k, blockIdx.x, target);
+  else bicg_b_body<NF, true>(c, k, blockIdx.x - c.nagg, target);
 }
 
 // Plain y = A x with the UNSCALED matrix (parity hook, partitioned driver); same tiling as the Krylov kernels.

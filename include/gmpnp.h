@@ -175,6 +175,10 @@ int64_t gmpnp_n_dofs(const gmpnp_solver* s);
 int64_t gmpnp_n_blocks(const gmpnp_solver* s);   /* node blocks of the BSR Jacobian */
 int64_t gmpnp_jacobian_nnz(const gmpnp_solver* s); /* n_blocks * n_fields^2 */
 int32_t gmpnp_n_aggregates(const gmpnp_solver* s);
+/* Kernel launches per BiCGStab iteration of the 3D solver: 4 (coarse, tile, coarse, tile) or 2 (the coarse workgroups
+ * ride inside the tile launches; chosen when all workgroups of a launch are resident at once, GMPNP_FUSED_HALF=0/1
+ * overrides). Diagnostics for the bench; no reference counterpart. */
+int32_t gmpnp_krylov_launches_per_iteration(const gmpnp_solver* s);
 
 /* b = assemble(F) with bc rows b = x - g; optionally A = assemble(J) with identity bc rows (kept on device).
  * F_out (n_dofs) and norm_out may be NULL. */

@@ -23,11 +23,13 @@ def per_launch(kernel):
     w = [v for k, v in out["WRITE_SIZE"].items() if kernel in k][0]["mean_KB"]
     return 2.0 * f * 1024.0 + w * 1024.0
 
-a, b = per_launch("k_bicg_a<9>"), per_launch("k_bicg_b<9>")
+fused = any("k_half_a<9>" in k for k in out["FETCH_SIZE"])  # two-launch form: the coarse workgroups ride inside the tile launches
+ka, kb = ("k_half_a<9>", "k_half_b<9>") if fused else ("k_bicg_a<9>", "k_bicg_b<9>")
+a, b = per_launch(ka), per_launch(kb)
 json.dump({
     "source": "profiles/r01/bench_steps3_pmc_fetch_write.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 --warmup 1`)",
     "correction": "bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024; the factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM / rocprofv3 section), calibrated here for the solver's own access width (tools/calib_fetch.hip: a 2 GiB stream read with 8 B per lane / 63 active lanes reports FETCH_SIZE*1024 = 0.500005 of the bytes, same as 16 B per lane)",
-    "k_bicg_a_bytes_per_launch": a, "k_bicg_b_bytes_per_launch": b, "hbm_bytes_per_launch": 0.5 * (a + b),
+    "kernels": [ka, kb], "a_bytes_per_launch": a, "b_bytes_per_launch": b, "hbm_bytes_per_launch": 0.5 * (a + b),
     "note": "memory-side (L2 miss) traffic; Infinity-Cache hits are included in FETCH_SIZE, so this is an upper bound on HBM bytes for this < 60 MB working set",
 }, open(os.path.join(ROOT, "profiles", "r01_spmv_pmc.json"), "w"), indent=1)
-print("k_bicg_a %.2f MB, k_bicg_b %.2f MB per launch" % (a / 1e6, b / 1e6))
+print("%s %.2f MB, %s %.2f MB per launch" % (ka, a / 1e6, kb, b / 1e6))
