@@ -348,6 +348,31 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
 
 
+def _run_pore10(monkeypatch, nsteps=3, **env):
+    from gmpnp_amd.pore3d import PoreRun
+    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)  # read by gmpnp_create
+    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=10e-9, R=5e-9)
+    try:
+        run.run(verbose=False)
+        return np.array(run.history[1:]), list(run.newton_its), run.sys.dev.krylov_launches_per_iteration
+    finally:
+        run.sys.close()
+
+
+def test_solver_variants_agree(monkeypatch, gpu_lib):
+    """The launch form must not change a single bit (same arithmetic, different hand-over); warm starts and coarse reuse
+    change the Krylov path only: Newton counts identical, states equal to the linear-solve tolerance."""
+    ref, its, launches = _run_pore10(monkeypatch)
+    assert launches == 2  # L_10_R_5: every workgroup of a launch is resident
+    unfused, its_u, launches_u = _run_pore10(monkeypatch, GMPNP_FUSED_HALF="0")
+    assert launches_u == 4 and its_u == its and np.array_equal(unfused, ref)
+    cold, its_c, _ = _run_pore10(monkeypatch, GMPNP_WARM_START="0", GMPNP_COARSE_LAG="1")
+    assert its_c == its and relerr(cold.ravel(), ref.ravel()) < 1e-8
+
+
 # field_OHP [V/nm] and eps_rel_OHP "obtained from solving the MPNP code", reference 1D/Stern_CO2ER.py:66-68 — the only
 # outputs of the hot path the reference holds.  Configuration (not stated there, verified in SURVEY §8c): the 1D
 # defaults, K+, 0.1 M KHCO3, MPNP, 50 um mesh.
