@@ -40,7 +40,7 @@ struct KrylovScalars {
   double tol;        // absolute threshold on ||r||_2 (host)
   double rr;         // ||r||_2^2 seen by the last convergence test (B)
   int32_t iters;     // completed iterations (B)
-  int32_t it_cur;    // iteration index of the A kernel in flight (A)
+  int32_t it_cur;    // unused (the iteration index is a kernel argument); kept for the struct layout
   int32_t max_iters; // host
   int32_t done;      // 1 = converged, 2 = max_iters, 3 = breakdown (published by B)
   int32_t done_next; // verdict of coarse_b(k), turned into `done` by B(k)

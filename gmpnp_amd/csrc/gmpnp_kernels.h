@@ -4,7 +4,11 @@
 //   k_res_gather   race-free node gather of the residual, Dirichlet rows b = x - g, ||b||^2      (a5, a6)
 //   k_jac_gather   race-free gather of the node-block Jacobian straight into SELL storage,
 //                  identity Dirichlet rows                                                        (a5, a6)
-//   k_bicg_a/b     fused BiCGStab half-iterations: vector updates + coarse solve + SELL SpMV + dots (a7)
+//   k_block_inverse, k_scale_columns, k_coarse_rows/_sum/_reduce/_invert
+//                  preconditioner set-up: node-block inverses, As = J Dinv, Galerkin coarse operator, its inverse   (a7)
+//   k_coarse_a/b, k_bicg_a/b  (four launches per iteration)  or  k_half_a/b  (two: coarse workgroups inside the tile launch)
+//                  fused right-preconditioned BiCGStab: scalars + coarse solve, vector updates + SELL SpMV + dots    (a7)
+//   k_bcr_*, k_tri_*   1D: block cyclic reduction of the block-tridiagonal Jacobian (direct solve)                   (a7)
 //
 // Reference mathematics: 3D/MPNP_CO2ER_pore.py:505-769, 1D/MPNP_CO2ER_EDL.py:383-595.
 #pragma once
@@ -1469,9 +1473,26 @@ __global__ __launch_bounds__(kVecBlock) void k_true_residual(const double* __res
   if (threadIdx.x == 0) part[blockIdx.x] = w[0];
 }
 
-__global__ void k_scale(double* __restrict__ x, double a, int n) {
+// Line search of a warm start: partials of (w,b), (w,w), (b,b) with w = J d (from k_spmv_plain), three per workgroup.
+__global__ __launch_bounds__(kVecBlock) void k_dots3(const double* __restrict__ w, const double* __restrict__ b,
+                                                     double* __restrict__ part, int n, int nblocks) {
+  __shared__ double lds[12];
+  const int i = blockIdx.x * kVecBlock + threadIdx.x;
+  double v[3] = {0.0, 0.0, 0.0};
+  if (i < n) { const double wi = w[i], bi = b[i]; v[0] = wi * bi; v[1] = wi * wi; v[2] = bi * bi; }
+  block_sum<3>(v, lds);
+  if (threadIdx.x == 0) { part[blockIdx.x] = v[0]; part[nblocks + blockIdx.x] = v[1]; part[2 * nblocks + blockIdx.x] = v[2]; }
+}
+// x0 = theta d, r0 = b - theta w
+__global__ void k_line_apply(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ b,
+                             const double* __restrict__ w, double theta, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= a;
+  if (i < n) { x[i] *= theta; r[i] = b[i] - theta * w[i]; }
+}
+// step = a - b (total update of a Newton solve, kept as the search direction of the next step's first linear solve)
+__global__ void k_diff(double* __restrict__ d, const double* __restrict__ a, const double* __restrict__ b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = a[i] - b[i];
 }
 
 // warm start of the next Newton correction: x <- a x + b xp, xp <- old x  (x = dx_k, xp = dx_{k-1})
