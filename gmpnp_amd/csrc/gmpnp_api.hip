@@ -86,6 +86,7 @@ struct gmpnp_solver {
   bool jacobian_valid = false, precond_valid = false;
   int precond_mode = -1;
   int precond_lag = 1;  // rebuild Dinv / coarse inverse every precond_lag-th Newton iteration of a solve
+  const double* shadow_src = nullptr; double shadow_rho0 = 0.0;  // experiment: shadow vector of the next krylov() call
   bool have_step = false;       // kstep holds the total update of the previous Newton solve (same time series)
   bool state_jumped = true;     // u was set from outside since the last Newton solve: the Jacobian moves a lot, no coarse reuse
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
@@ -324,13 +325,15 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   s->c.use_coarse = use_coarse;
   const int n = s->ndof;
-  hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr, s->kr.p, n);
+  // shadow vector: r_0, or (experiment, GMPNP_SHADOW_B=1) the original right-hand side of a warm-started solve
+  hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr,
+                     s->shadow_src ? s->shadow_src : s->kr.p, n);
   HIP_TRY(hipMemsetAsync(s->ky.p, 0, n * sizeof(double), s->stream));
   if (s->fused_half) { HIP_TRY(hipMemsetAsync(s->ticket.p, 0, 16 * 66 * sizeof(uint32_t), s->stream)); s->fused_seq = 0; }
   if (use_coarse)  // P^T b partials where A(0) expects them
     hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->kr.p, s->cpart_v1.p);
   KrylovScalars init{};
-  init.rho[0] = init.rho[1] = bnorm * bnorm; init.alpha = 1.0;
+  init.rho[0] = init.rho[1] = s->shadow_src ? s->shadow_rho0 : bnorm * bnorm; init.alpha = 1.0;
   init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.iters = 0; init.it_cur = 0;
   init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
@@ -448,6 +451,8 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       hipLaunchKernelGGL(k_line_apply, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kr.p, (const double*)s->kb.p,
                          (const double*)s->kt.p, theta, n);
       warm = true; rhs_norm = std::sqrt(rn2);
+      static const bool shadow_b = std::getenv("GMPNP_SHADOW_B") && std::atoi(std::getenv("GMPNP_SHADOW_B"));
+      if (shadow_b) { s->shadow_src = s->kb.p; s->shadow_rho0 = bb - theta * wb; }  // (b, r0)
     }  // else: kr still holds b, cold start
   }
   for (int pass = 0;; ++pass) {
@@ -460,6 +465,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       const int uc = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
       const int cap = (pass == 0 && warm) ? std::min(maxit, 3 * std::max(60, s->last_krylov_iters[uc])) : maxit;
       rc = krylov<NF>(s, mode, rhs_norm, 0.0, tol, cap, &ls, pass > 0);
+      s->shadow_src = nullptr;
     }
     total.iterations += ls.iterations; total.converged = ls.converged; total.residual_norm = ls.residual_norm;
     if (rc == GMPNP_ERR_LINEAR && pass == 0 && warm) {
