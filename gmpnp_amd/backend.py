@@ -28,6 +28,7 @@ EXPORTS = [
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
+    "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
 ]
 
 
@@ -109,6 +110,10 @@ def load_library(path: str = None):
     lib.gmpnp_linear_solve.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), c_int32, c_double, c_double,
                                        c_int32, POINTER(CLinearStats)]
     lib.gmpnp_precond_apply.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_set_state_device.argtypes = [c_void_p, c_void_p, c_void_p]      # raw device addresses (tensor.data_ptr())
+    lib.gmpnp_assemble_device.argtypes = [c_void_p, c_int32, c_void_p, POINTER(c_double)]
+    lib.gmpnp_spmv_device.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.gmpnp_precond_apply_device.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
     lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
     lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
     lib.gmpnp_event_overhead.argtypes = [c_void_p, c_int32, POINTER(c_double)]
@@ -329,6 +334,22 @@ class DeviceSolver:
         z = np.empty(self.ndof)
         self._check(self.lib.gmpnp_precond_apply(self._h, linear_solver, _dptr(r), _dptr(z)))
         return z
+
+    # ---- device-pointer variants: arguments are device addresses (e.g. ``torch.Tensor.data_ptr()`` of contiguous fp64
+    # tensors of length ndof on this handle's GPU, file vertex order); the caller synchronises its own stream first ----
+    def set_state_device(self, u_ptr=None, un_ptr=None):
+        self._check(self.lib.gmpnp_set_state_device(self._h, u_ptr, un_ptr))
+
+    def assemble_device(self, F_ptr, want_jacobian=True):
+        norm = c_double()
+        self._check(self.lib.gmpnp_assemble_device(self._h, int(bool(want_jacobian)), F_ptr, byref(norm)))
+        return norm.value
+
+    def spmv_device(self, x_ptr, y_ptr):
+        self._check(self.lib.gmpnp_spmv_device(self._h, x_ptr, y_ptr))
+
+    def precond_apply_device(self, r_ptr, z_ptr, linear_solver=LINEAR_TWOLEVEL):
+        self._check(self.lib.gmpnp_precond_apply_device(self._h, linear_solver, r_ptr, z_ptr))
 
     def newton_solve(self, options: CNewtonOptions, error_on_nonconvergence=True):
         """``solve(F == 0, u, bcs, solver_parameters)`` on the device state.  Raises RuntimeError on

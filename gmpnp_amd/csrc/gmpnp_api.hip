@@ -92,6 +92,7 @@ struct gmpnp_solver {
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
   int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
   DevBuf<uint32_t> ticket;
+  DevBuf<int32_t> perm_dev;  // file vertex of each internal node (device-pointer entry points)
   bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); GMPNP_FUSED_HALF=1
   unsigned fused_seq = 0;   // fused launches so far in the current solve
   int warm_start = 2;  // start Newton iteration k+1's linear solve from (1 - omega) dx_k (GMPNP_WARM_START=0 disables)
@@ -689,6 +690,21 @@ int download_vec(gmpnp_solver* s, const double* dev, double* file_order) {
   return GMPNP_OK;
 }
 
+// device-resident vectors in file order (partitioned solve: torch tensors, never staged through the host)
+int import_dev(gmpnp_solver* s, const double* file_order_dev, double* internal) {
+  hipLaunchKernelGGL(k_to_internal, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, internal, file_order_dev,
+                     (const int32_t*)s->perm_dev.p, s->nf, (int)s->ndof);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+int export_dev(gmpnp_solver* s, const double* internal, double* file_order_dev) {
+  hipLaunchKernelGGL(k_to_file, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, file_order_dev, internal,
+                     (const int32_t*)s->perm_dev.p, s->nf, (int)s->ndof);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return GMPNP_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -775,6 +791,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
+  HIP_TRY(s->perm_dev.upload(t.perm));
   HIP_TRY(s->ticket.alloc(16 * 66));  // counter + 64 replicated flags, one cache line each
   HIP_TRY(s->part_a.alloc((size_t)2 * t.ntiles));  // (rhat,v) partials, then ||r||^2 partials
   HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
@@ -1016,6 +1033,53 @@ int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* 
   GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
   if (rc) return rc;
   return download_vec(s, s->kx.p, z);
+}
+
+// ---- device-pointer variants (vectors in file order, resident on the handle's device; the caller has finished writing
+// the inputs before the call, the outputs are complete at return) -------------------------------------------------------
+int gmpnp_set_state_device(gmpnp_solver* s, const double* u_dev, const double* u_n_dev) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  if (u_dev) { int rc = import_dev(s, u_dev, s->u.p); if (rc) return rc; s->state_jumped = true; }
+  if (u_n_dev) { int rc = import_dev(s, u_n_dev, s->un.p); if (rc) return rc; }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->jacobian_valid = false;
+  return GMPNP_OK;
+}
+int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev, double* norm_out) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  int rc = gmpnp_assemble(s, want_jacobian, nullptr, norm_out);
+  if (rc) return rc;
+  return F_dev ? export_dev(s, s->F.p, F_dev) : GMPNP_OK;
+}
+int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev) {
+  if (!s || !x_dev || !y_dev) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  int rc = import_dev(s, x_dev, s->kx.p); if (rc) return rc;
+  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
+                                       (const double*)s->kx.p, s->kt.p));
+  return export_dev(s, s->kt.p, y_dev);
+}
+int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t mode, const double* r_dev, double* z_dev) {
+  if (!s || !r_dev || !z_dev) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
+    return fail(GMPNP_ERR_INVALID, "preconditioner kinds: two-level or Jacobi");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  int rc;
+  if (!s->precond_valid || s->precond_mode != mode) {
+    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+    GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (*s->h_status & 14) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
+  }
+  rc = import_dev(s, r_dev, s->ky.p); if (rc) return rc;
+  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
+  if (rc) return rc;
+  return export_dev(s, s->kx.p, z_dev);
 }
 
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {

@@ -1495,6 +1495,16 @@ __global__ void k_diff(double* __restrict__ d, const double* __restrict__ a, con
   if (i < n) d[i] = a[i] - b[i];
 }
 
+// file vertex order <-> internal order on the device (device-pointer entry points of the partitioned solve)
+__global__ void k_to_internal(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int nf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int I = i / nf, f = i - I * nf; dst[i] = src[(size_t)perm[I] * nf + f]; }
+}
+__global__ void k_to_file(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int nf, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int I = i / nf, f = i - I * nf; dst[(size_t)perm[I] * nf + f] = src[i]; }
+}
+
 // warm start of the next Newton correction: x <- a x + b xp, xp <- old x  (x = dx_k, xp = dx_{k-1})
 __global__ void k_warm_start(double* __restrict__ x, double* __restrict__ xp, double a, double b, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

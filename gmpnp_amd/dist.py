@@ -11,11 +11,15 @@ so the rows of owned vertices are complete without any matrix communication; gho
 (they are never used).  Communication per Newton iteration: one ghost exchange of u; per Krylov iteration: two ghost
 exchanges (one per operator application) and the BiCGStab scalars as fused all-reduces of 5 / 2 doubles.
 
-The Krylov loop runs on the host in this module (right-preconditioned BiCGStab, same recurrences as the device
-solver), calling the rank's backend for the three local operations: assemble, y = A_local x, z = M_local^{-1} r
-(subdomain node-block Jacobi + slab coarse correction: an additive Schwarz preconditioner with minimal overlap).
-On a 3.7k-vertex mesh this cannot beat one GPU — an RCCL small-message all-reduce costs more than the local SpMV — and
-the per-call host copies of this first version dominate; the mapping that scales is one problem per GPU (bench.py).
+The Krylov loop is driven from this module (right-preconditioned BiCGStab, same recurrences as the device solver),
+calling the rank's backend for the three local operations: assemble, y = A_local x, z = M_local^{-1} r (subdomain
+node-block Jacobi + slab coarse correction: an additive Schwarz preconditioner with minimal overlap).  The vectors are
+either NumPy arrays (``DeviceLocalOps``: every call crosses the C-ABI with host buffers; also what the CPU tests'
+doubles use) or torch tensors resident on the GPU (``TorchDeviceLocalOps``: the ``*_device`` entry points of the
+library take the tensors' device addresses, the ghost exchange and the all-reduces run on the tensors through
+``torch.distributed`` — RCCL on a multi-GPU node, nothing is staged through the host).  On a 3.7k-vertex mesh neither
+can beat one GPU — an RCCL small-message all-reduce costs more than the local SpMV — the mapping that scales there is
+one problem per GPU (bench.py, gmpnp_amd.sweep).
 """
 from __future__ import annotations
 
@@ -25,6 +29,33 @@ from dataclasses import dataclass
 import numpy as np
 
 from .problem import Problem
+
+
+# ---------------------------------------------------------------------------------------------
+# the solvers below work on NumPy arrays or on torch tensors (CPU or GPU) alike
+# ---------------------------------------------------------------------------------------------
+def _is_torch(a):
+    return type(a).__module__.split(".")[0] == "torch"
+
+
+def _copy(a):
+    return a.clone() if _is_torch(a) else a.copy()
+
+
+def _dot(a, b):
+    if _is_torch(a):
+        if not a.is_cuda:  # host tensors: the very arithmetic of the NumPy path
+            return float(np.dot(a.numpy(), b.numpy()))
+        import torch
+        return float(torch.dot(a, b))
+    return float(np.dot(a, b))
+
+
+def _zeros_like(a):
+    if _is_torch(a):
+        import torch
+        return torch.zeros_like(a)
+    return np.zeros_like(a)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -129,6 +160,7 @@ class Comm:
         self.dom = dom
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.device = device if device is not None else "cpu"
+        self._idx_cache = {}
 
     def allreduce_sum(self, values):
         a = np.asarray(values, dtype=np.float64)
@@ -138,10 +170,38 @@ class Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
+    def _index(self, idx, device):
+        key = (id(idx), str(device))
+        if key not in self._idx_cache:
+            self._idx_cache[key] = self.torch.as_tensor(np.asarray(idx), dtype=self.torch.long, device=device)
+        return self._idx_cache[key]
+
+    def _exchange_torch(self, x):
+        """Same plan on a torch tensor: gather the send rows on the tensor's device, move them only if the communication
+        backend needs another device (gloo: host; nccl = RCCL: none), scatter the received rows back."""
+        nf = self.dom.nf
+        x2 = x.view(-1, nf)
+        ops, bufs = [], []
+        for q, idx in sorted(self.dom.send.items()):
+            t = x2.index_select(0, self._index(idx, x.device)).to(self.device).contiguous()
+            ops.append(self.dist.P2POp(self.dist.isend, t, q))
+        for q, idx in sorted(self.dom.recv.items()):
+            t = self.torch.empty((len(idx), nf), dtype=self.torch.float64, device=self.device)
+            bufs.append((idx, t))
+            ops.append(self.dist.P2POp(self.dist.irecv, t, q))
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()
+        for idx, t in bufs:
+            x2.index_copy_(0, self._index(idx, x.device), t.to(x.device))
+        return x
+
     def exchange(self, x):
         """Overwrite the ghost entries of the local vector x (n_local*nf) with the owners' values."""
         if not self.active:
             return x
+        if _is_torch(x):
+            return self._exchange_torch(x)
         nf = self.dom.nf
         x2 = x.reshape(-1, nf)
         ops, bufs = [], []
@@ -185,6 +245,51 @@ class DeviceLocalOps:
         self.dev.close()
 
 
+class TorchDeviceLocalOps:
+    """The same three operations on torch tensors that live on the handle's GPU: nothing crosses the host.  Vectors are
+    contiguous fp64 tensors of length n_local*nf in the local (file) vertex order; the library reads/writes them through
+    their device addresses (``gmpnp_*_device``) on its own stream, so the torch stream is drained before each call."""
+
+    def __init__(self, dom: LocalDomain, linear_solver=0, device_id=0, **device_kwargs):
+        import torch
+        from . import backend
+        self.torch, self.backend = torch, backend
+        self.device = torch.device("cuda", device_id)
+        self.dev = backend.DeviceSolver(dom.problem, device_id=device_id, **device_kwargs)
+        self.mode = linear_solver
+
+    def tensor(self, a):
+        """NumPy -> resident tensor (set-up and tests only)."""
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+
+    def _ready(self, *ts):
+        for t in ts:
+            assert t.is_cuda and t.dtype == self.torch.float64 and t.is_contiguous() and t.numel() == self.dev.ndof
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def assemble(self, u, un, want_jacobian):
+        F = self.torch.empty_like(u)
+        self._ready(u, un, F)
+        self.dev.set_state_device(u.data_ptr(), un.data_ptr())
+        self.dev.assemble_device(F.data_ptr(), want_jacobian)
+        return F
+
+    def spmv(self, x):
+        y = self.torch.empty_like(x)
+        self._ready(x, y)
+        self.dev.spmv_device(x.data_ptr(), y.data_ptr())
+        return y
+
+    def precond(self, r):
+        z = self.torch.empty_like(r)
+        self._ready(r, z)
+        self.dev.precond_apply_device(r.data_ptr(), z.data_ptr(), self.mode)
+        return z
+
+    def close(self):
+        self.dev.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # distributed BiCGStab + Newton
 # ---------------------------------------------------------------------------------------------
@@ -194,11 +299,11 @@ def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=1
     n = len(b)
 
     def dots(pairs):
-        return comm.allreduce_sum([float(np.dot(a[own], c[own])) for a, c in pairs])
+        return comm.allreduce_sum([_dot(a[own], c[own]) for a, c in pairs])
 
     def apply(p):
         """A M^{-1} p on owned rows (ghost entries of the result are zeroed)."""
-        pin = p.copy()
+        pin = _copy(p)
         pin[own.stop:] = 0.0
         z = ops.precond(pin)
         z[own.stop:] = 0.0
@@ -207,16 +312,16 @@ def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=1
         y[own.stop:] = 0.0
         return y, z
 
-    r = b.copy()
+    r = _copy(b)
     r[own.stop:] = 0.0
-    rhat = r.copy()
+    rhat = _copy(r)
     bnorm = np.sqrt(dots([(r, r)])[0])
     tol = max(rtol * bnorm, atol)
-    y = np.zeros(n)
+    y = _zeros_like(b)
     if not bnorm > 0.0:
-        return np.zeros(n), 0, True
+        return _zeros_like(b), 0, True
     rho = bnorm * bnorm
-    p = r.copy()
+    p = _copy(r)
     it = 0
     tiny = np.finfo(np.float64).tiny
 
@@ -226,8 +331,8 @@ def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=1
         Ay, _ = apply(y)
         r = b - Ay
         r[own.stop:] = 0.0
-        rhat = r.copy()
-        p = r.copy()
+        rhat = _copy(r)
+        p = _copy(r)
         rho = dots([(r, r)])[0]
         return np.sqrt(rho) <= tol
 
@@ -264,7 +369,7 @@ def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=1
         beta = (rho_new / rho) * (alpha / omega)
         p = r + beta * (p - omega * v)
         rho = rho_new
-    yin = y.copy()
+    yin = _copy(y)
     yin[own.stop:] = 0.0
     x = ops.precond(yin)
     x[own.stop:] = 0.0
@@ -277,13 +382,13 @@ def newton_solve(ops, comm: Comm, dom: LocalDomain, u, un, maximum_iterations=50
                  error_on_nonconvergence=True):
     """[3P] dolfin::NewtonSolver semantics (SURVEY §3.3) on a partitioned state; u, un are local (owned+ghost)."""
     own = dom.owned_dofs()
-    u = comm.exchange(u.copy())
-    un = comm.exchange(un.copy())
+    u = comm.exchange(_copy(u))
+    un = comm.exchange(_copy(un))
 
     def residual(want_j):
         F = ops.assemble(u, un, want_j)
         F[own.stop:] = 0.0
-        return F, float(np.sqrt(comm.allreduce_sum([float(np.dot(F[own], F[own]))])[0]))
+        return F, float(np.sqrt(comm.allreduce_sum([_dot(F[own], F[own])])[0]))
 
     stats = {"iterations": 0, "residuals": [], "krylov_per_iteration": [], "converged": False}
     b, r = residual(False)
@@ -316,6 +421,8 @@ def newton_solve(ops, comm: Comm, dom: LocalDomain, u, un, maximum_iterations=50
 def gather_global(comm: Comm, dom: LocalDomain, u_local, nv_global):
     """Assemble the global (file-order) state on every rank from the owned parts (all-reduce of disjoint pieces)."""
     nf = dom.nf
+    if _is_torch(u_local):
+        u_local = u_local.detach().cpu().numpy()
     out = np.zeros(nv_global * nf)
     o2 = out.reshape(nv_global, nf)
     o2[dom.owned] = u_local.reshape(-1, nf)[:dom.n_owned]

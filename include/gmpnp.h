@@ -196,6 +196,16 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t line
  * the Krylov loop runs across ranks and each rank applies its subdomain preconditioner. */
 int gmpnp_precond_apply(gmpnp_solver* s, int32_t linear_solver, const double* r, double* z);
 
+/* Device-pointer variants for the mesh-partitioned solve (gmpnp_amd/dist.py keeps its vectors as torch tensors on the
+ * GPU and exchanges ghosts with RCCL): same semantics as gmpnp_set_state / gmpnp_assemble / gmpnp_spmv /
+ * gmpnp_precond_apply, but every vector pointer is DEVICE memory of the handle's GPU (file vertex order). Inputs must be
+ * complete before the call (synchronise the producing stream); outputs are complete at return. No reference counterpart
+ * (the reference is serial). */
+int gmpnp_set_state_device(gmpnp_solver* s, const double* u_dev, const double* u_n_dev);
+int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev, double* residual_norm);
+int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev);
+int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t kind, const double* r_dev, double* z_dev);
+
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
  * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming

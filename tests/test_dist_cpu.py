@@ -31,6 +31,24 @@ class OracleLocalOps:
         return self.lu.solve(r)
 
 
+class TorchOracleLocalOps(OracleLocalOps):
+    """The same double behind torch tensors: exercises the tensor code path of dist.bicgstab / newton_solve / Comm (the path
+    TorchDeviceLocalOps takes on the GPU) without a GPU."""
+
+    def _t(self, a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def assemble(self, u, un, want_jacobian):
+        return self._t(super().assemble(u.numpy(), un.numpy(), want_jacobian))
+
+    def spmv(self, x):
+        return self._t(super().spmv(x.numpy()))
+
+    def precond(self, r):
+        return self._t(super().precond(r.numpy()))
+
+
 def _small_problem():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import box_pore_problem
@@ -60,7 +78,7 @@ def test_partition_and_halo_plan():
         assert all(abs(q - d.rank) == 1 for d in doms for q in d.recv)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, use_torch=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as tdist
@@ -74,11 +92,13 @@ def _worker(rank, world, port, out_dir):
         owner = dist.slab_owner(prob.coords, prob.cells, world)
         dom = dist.build_local_domain(prob, owner, rank, world)
         comm = dist.Comm(dom)
-        ops = OracleLocalOps(dom)
+        ops = TorchOracleLocalOps(dom) if use_torch else OracleLocalOps(dom)
         # the whole first Newton solve of time step 0 (zero initial guess, as the reference)
         un = np.tile(np.r_[np.ones(8), 0.0], nv)
-        u, st = dist.newton_solve(ops, comm, dom, dist.scatter_local(dom, np.zeros(nv * 9)), dist.scatter_local(dom, un),
-                                  relaxation_parameter=0.9, krylov_rtol=1e-11, krylov_maxit=3000)
+        u0, un0 = dist.scatter_local(dom, np.zeros(nv * 9)), dist.scatter_local(dom, un)
+        if use_torch:
+            u0, un0 = ops._t(u0), ops._t(un0)
+        u, st = dist.newton_solve(ops, comm, dom, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-11, krylov_maxit=3000)
         ug = dist.gather_global(comm, dom, u, nv)
         if rank == 0:
             np.savez(os.path.join(out_dir, "dist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
@@ -87,7 +107,8 @@ def _worker(rank, world, port, out_dir):
         tdist.destroy_process_group()
 
 
-def test_partitioned_newton_matches_serial_oracle(tmp_path):
+@pytest.mark.parametrize("use_torch", [False, True])
+def test_partitioned_newton_matches_serial_oracle(tmp_path, use_torch):
     import socket
     import torch.multiprocessing as mp
     import gmpnp_oracle as O
@@ -95,7 +116,7 @@ def test_partitioned_newton_matches_serial_oracle(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_torch), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "dist.npz"))
     prob = _small_problem()
     nv = prob.coords.shape[0]

@@ -398,7 +398,7 @@ def test_reference_recorded_ohp_field_and_permittivity(voltage, tmp_path, monkey
     assert abs(meta["eps_rel_OHP"] / eps - 1.0) < 0.003
 
 
-def _partition_worker(rank, world, port, out_dir):
+def _partition_worker(rank, world, port, out_dir, resident=False):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -418,11 +418,14 @@ def _partition_worker(rank, world, port, out_dir):
         owner = dist.slab_owner(prob.coords, prob.cells, world)
         dom = dist.build_local_domain(prob, owner, rank, world)
         comm = dist.Comm(dom)
-        ops = dist.DeviceLocalOps(dom)
+        # resident: vectors are torch tensors on the GPU and the library works on their device addresses
+        ops = dist.TorchDeviceLocalOps(dom) if resident else dist.DeviceLocalOps(dom)
         try:
             un = np.tile(np.r_[np.ones(8), 0.0], nv)
-            u, st = dist.newton_solve(ops, comm, dom, dist.scatter_local(dom, np.zeros(nv * 9)),
-                                      dist.scatter_local(dom, un), relaxation_parameter=0.9, krylov_rtol=1e-11)
+            u0, un0 = dist.scatter_local(dom, np.zeros(nv * 9)), dist.scatter_local(dom, un)
+            if resident:
+                u0, un0 = ops.tensor(u0), ops.tensor(un0)
+            u, st = dist.newton_solve(ops, comm, dom, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-11)
             ug = dist.gather_global(comm, dom, u, nv)
         finally:
             ops.close()
@@ -433,7 +436,8 @@ def _partition_worker(rank, world, port, out_dir):
         tdist.destroy_process_group()
 
 
-def test_partitioned_solve_matches_serial(tmp_path, gpu_lib):
+@pytest.mark.parametrize("resident", [False, True])
+def test_partitioned_solve_matches_serial(tmp_path, gpu_lib, resident):
     """Two ranks (two processes on this box's single GPU, gloo for the exchange): mesh-partitioned Newton solve with the
     HIP backend doing the local assembly / SpMV / subdomain preconditioner = the serial result (golden pore10 step 0)."""
     import socket
@@ -442,7 +446,7 @@ def test_partitioned_solve_matches_serial(tmp_path, gpu_lib):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_partition_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_partition_worker, args=(2, port, str(tmp_path), resident), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "dist.npz"))
     g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
     assert int(got["its"]) == int(g["newton_its"][0])
