@@ -1,0 +1,49 @@
+"""Mesh-partitioned Newton solve of time step 0 of L_50_R_5 with device-resident vectors: wall time per Newton iteration.
+Rehearsal on a one-GPU box: the ranks share the card and talk through gloo (on a multi-GPU node: backend nccl = RCCL, one
+rank per GPU).
+
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/partitioned_probe.py [backend]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as tdist
+from gmpnp_amd import dist
+from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+from gmpnp_amd.params import pore_parameters, utilities_dir
+from gmpnp_amd.problem import pore_problem
+
+backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+torch.cuda.set_device(local)
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        tdist.init_process_group(backend)
+pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
+mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+prob, _ = pore_problem(pp, mesh)
+nv = mesh.num_vertices
+owner = dist.slab_owner(prob.coords, prob.cells, world)
+dom = dist.build_local_domain(prob, owner, rank, world)
+comm = dist.Comm(dom, device=("cuda:%d" % local) if backend == "nccl" else "cpu")
+ops = dist.TorchDeviceLocalOps(dom, device_id=local)
+un = np.tile(np.r_[np.ones(8), 0.0], nv)
+u0, un0 = ops.tensor(dist.scatter_local(dom, np.zeros(nv * 9))), ops.tensor(dist.scatter_local(dom, un))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+u, st = dist.newton_solve(ops, comm, dom, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-10)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+if rank == 0:
+    print("ranks %d (%s): %d owned + %d ghost vertices on rank 0; Newton %d its, Krylov %s, %.3f s -> %.2f Newton its/s, %.0f us per Krylov iteration"
+          % (world, backend, dom.n_owned, len(dom.ghosts), st["iterations"], st["krylov_per_iteration"], dt, st["iterations"] / dt,
+             1e6 * dt / max(1, sum(st["krylov_per_iteration"]))))
+ops.close()
+if world > 1:
+    tdist.destroy_process_group()
