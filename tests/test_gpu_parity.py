@@ -348,6 +348,36 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
 
 
+def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):
+    """One uniform refinement of L_10_R_5 (12.9k vertices, 116k dofs): more tiles than resident workgroup slots (four-launch
+    iteration) and more tiles per aggregate than the prologues preload (tail loops of the partial sums).  Assembly and
+    SpMV against the oracle, the Krylov solve against the oracle matrix, Newton by its contraction property."""
+    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+    from gmpnp_amd.params import pore_parameters, utilities_dir
+    from gmpnp_amd.problem import pore_problem
+    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    prob, _ = pore_problem(pp, mesh, refine=1)
+    nv = prob.coords.shape[0]
+    assert nv > 12000
+    u, un = random_state(nv, 8, seed=11)
+    Fo, Ao = O.assemble(prob, u, un)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        assert dev.krylov_launches_per_iteration == 4
+        dev.set_state(u, un)
+        F, _ = dev.assemble(True)
+        assert relerr(F, Fo) < 1e-12
+        x = np.random.default_rng(12).standard_normal(prob.ndof)
+        assert relerr(dev.spmv(x), Ao @ x) < 1e-13
+        xs, st = dev.linear_solve(Fo, gpu_lib.LINEAR_TWOLEVEL, 1e-10, 0.0, 20000)
+        assert st["converged"] and relerr(Ao @ xs, Fo) < 1e-8
+        dev.set_state(np.zeros(prob.ndof), np.tile(np.r_[np.ones(8), 0.0], nv))
+        stn = dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        r = np.array(stn["residuals"])
+        assert stn["converged"] and 5 <= stn["iterations"] <= 9
+        assert np.allclose(r[3:] / r[2:-1], 0.1, rtol=0.3)
+
+
 def _run_pore10(monkeypatch, nsteps=3, **env):
     from gmpnp_amd.pore3d import PoreRun
     for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG"):
