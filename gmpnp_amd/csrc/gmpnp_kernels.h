@@ -918,7 +918,10 @@ __device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned target, int t
     const unsigned* flag = c.ticket + 16 * (1 + (tile & (kFlagCopies - 1)));
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (wall_clock64() - t0 > 500000ull) {  // 5 ms at 100 MHz: never in a healthy run; ends the solve (later launches exit at once)
+      // 2 s at 100 MHz.  The flag cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
+      // budget only has to outlast a time slice taken by another process sharing the GPU.  Ends the solve (later
+      // launches exit at once).
+      if (wall_clock64() - t0 > 200000000ull) {
         ok = 0; atomicOr(c.status, 8); c.scal->done = 3; break;
       }
       __builtin_amdgcn_s_sleep(2);
