@@ -87,6 +87,8 @@ struct gmpnp_solver {
   int precond_mode = -1;
   int precond_lag = 1;  // rebuild Dinv / coarse inverse every precond_lag-th Newton iteration of a solve
   const double* shadow_src = nullptr; double shadow_rho0 = 0.0;  // experiment: shadow vector of the next krylov() call
+  int last_done = 0;            // exit code of the last device Krylov loop (1 converged, 2 iteration cap, 3 breakdown / divergence)
+  DevBuf<double> krand;         // pseudo-random shadow vector for a pass that follows a breakdown
   bool have_step = false;       // kstep holds the total update of the previous Newton solve (same time series)
   bool state_jumped = true;     // u was set from outside since the last Newton solve: the Jacobian moves a lot, no coarse reuse
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
@@ -337,6 +339,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   init.rho[0] = init.rho[1] = s->shadow_src ? s->shadow_rho0 : bnorm * bnorm; init.alpha = 1.0;
   init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.iters = 0; init.it_cur = 0;
   init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
+  init.rr0 = bnorm * bnorm;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
   s->h_scal[0] = init;
   HIP_TRY(hipMemcpyAsync(s->scal.p, s->h_scal, sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
@@ -374,6 +377,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
     rc = drain_spmv_events(s); if (rc) return rc;
   }
   if (!restart) s->last_krylov_iters[use_coarse] = res.iters;
+  s->last_done = res.done;
   if (st) { st->iterations = res.iters; st->converged = (res.done == 1); st->residual_norm = std::sqrt(res.rr); st->rhs_norm = bnorm; }
   if (res.done != 1) {
     char buf[160];
@@ -456,39 +460,71 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       if (shadow_b) { s->shadow_src = s->kb.p; s->shadow_rho0 = bb - theta * wb; }  // (b, r0)
     }  // else: kr still holds b, cold start
   }
+  // Restarted BiCGStab.  A pass runs at most `restart_every` iterations; then (and after a breakdown) the true residual
+  // b - J x is formed with the unscaled matrix and the next pass starts from it with a fresh shadow vector.  This bounds
+  // the drift of the recursive residual, and it is what keeps BiCGStab from blowing up on the stiff systems of the
+  // thinnest pores (L_50_R_1: ||r|| reached 1e53 inside 10,000 unrestarted iterations, the reference's direct solver
+  // sails through).  A pass that ends in a breakdown or in a residual 1e5 times its start (device test) is thrown away
+  // and repeated with a pseudo-random shadow vector.  Short solves (the normal case) take exactly one pass and no check.
+  static const int restart_every = std::getenv("GMPNP_RESTART_EVERY") ? std::max(20, std::atoi(std::getenv("GMPNP_RESTART_EVERY"))) : 1000;
+  bool have_x = warm;      // kx holds a partial solution
+  bool random_shadow = false;
+  int bad_passes = 0;
   for (int pass = 0;; ++pass) {
     gmpnp_linear_stats_t ls{};
-    int rc;
-    if (pass == 0 && !warm) rc = krylov<NF>(s, mode, rhs_norm, rtol, atol, maxit, &ls);
-    else if (rhs_norm <= tol) { ls.converged = 1; ls.residual_norm = rhs_norm; rc = GMPNP_OK; }  // x0 is already good enough
+    int rc = GMPNP_OK;
+    const int cap = std::min(restart_every, maxit - total.iterations);
+    if (rhs_norm <= tol) { ls.converged = 1; ls.residual_norm = rhs_norm; s->last_done = 1; }  // nothing left to do
     else {
-      // a warm-started solve that needs more than 3x the previous solve's iterations is abandoned (cold repeat below)
-      const int uc = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
-      const int cap = (pass == 0 && warm) ? std::min(maxit, 3 * std::max(60, s->last_krylov_iters[uc])) : maxit;
-      rc = krylov<NF>(s, mode, rhs_norm, 0.0, tol, cap, &ls, pass > 0);
+      if (random_shadow) {  // (rhat, r0) of the new shadow vector
+        hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krand.p, (unsigned)(pass * 2654435761u), n);
+        hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->krand.p, (const double*)s->kr.p,
+                           s->part_f.p, n, s->n_resblocks);
+        HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        double wb = 0.0;
+        for (int i = 0; i < s->n_resblocks; ++i) wb += s->h_part[i];
+        s->shadow_src = s->krand.p; s->shadow_rho0 = wb;
+      }
+      const bool first_cold = (pass == 0 && !warm);
+      rc = krylov<NF>(s, mode, rhs_norm, first_cold ? rtol : 0.0, first_cold ? atol : tol, cap, &ls, pass > 0);
       s->shadow_src = nullptr;
     }
     total.iterations += ls.iterations; total.converged = ls.converged; total.residual_norm = ls.residual_norm;
-    if (rc == GMPNP_ERR_LINEAR && pass == 0 && warm) {
-      // BiCGStab can stagnate on one right-hand side and not on another: a failed warm-started solve is repeated cold
-      warm = false; rhs_norm = bnorm; pass = -1;
-      HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (rc && rc != GMPNP_ERR_LINEAR) { if (st) *st = total; return rc; }
+    const bool usable = (s->last_done == 1 || s->last_done == 2);  // converged or cap reached: y is a valid partial solution
+    if (usable && ls.iterations > 0) {
+      int rc2 = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, have_x ? 1.0 : 0.0, 1.0); if (rc2) return rc2;
+      have_x = true; random_shadow = false;
+    } else if (!usable) {
+      random_shadow = true; ++bad_passes;
+      if (std::getenv("GMPNP_DEBUG_WARM")) {
+        HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        KrylovScalars dbg; HIP_TRY(hipMemcpy(&dbg, s->scal.p, sizeof dbg, hipMemcpyDeviceToHost));
+        fprintf(stderr, "bad pass %d: its %d status %d rr %.3e rr0 %.3e rho %.3e %.3e alpha %.3e omega %.3e beta %.3e\n", pass, ls.iterations, *s->h_status,
+                dbg.rr, dbg.rr0, dbg.rho[0], dbg.rho[1], dbg.alpha, dbg.omega, dbg.beta);
+      }
       HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
-      continue;
+      if (!have_x) HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));  // kr was the work vector
     }
-    if (rc) { if (st) *st = total; return rc; }
-    if (ls.iterations > 0 || (pass == 0 && !warm)) {
-      rc = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, (pass == 0 && !warm) ? 0.0 : 1.0, 1.0); if (rc) return rc;
+    if (!have_x && s->last_done == 1) {  // zero right-hand side
+      HIP_TRY(hipMemsetAsync(s->kx.p, 0, n * sizeof(double), s->stream)); have_x = true;
     }
-    if (!(bnorm > 0.0) || (pass == 0 && ls.iterations <= verify_above)) break;  // short solves do not drift
-    double rn = 0.0;
-    rc = true_residual<NF>(s, &rn); if (rc) return rc;
+    if (!(bnorm > 0.0)) break;
+    if (pass == 0 && s->last_done == 1 && ls.iterations <= verify_above) break;  // short solves do not drift
+    double rn = rhs_norm;
+    if (have_x) { int rc2 = true_residual<NF>(s, &rn); if (rc2) return rc2; }  // kr = b - J x
     total.residual_norm = rn;
-    // Within 1000x of the target: accepted.  A 1e-10 solve of a small right-hand side ends at the attainable accuracy of
-    // b - J dx in fp64 (3-30x the target late in a run) and a restart cannot improve that; the check is there for gross
-    // drift (1e5x seen in plain Jacobi mode).  Otherwise restart, at most three times, and stop
-    // restarting as soon as a pass no longer halves the true residual.
-    if (rn <= 1e3 * tol || !(rn == rn) || pass == 3 || (pass > 0 && rn > 0.5 * rhs_norm)) break;
+    // Converged by the recurrence and within 1000x of the target by the true residual: accepted.  (A 1e-10 solve of a
+    // small right-hand side ends at the attainable accuracy of b - J dx in fp64, 3-30x the target late in a run.)
+    if (s->last_done == 1 && (rn <= 1e3 * tol || !(rn == rn))) break;
+    if (total.iterations >= maxit || bad_passes > 8 || !(rn == rn)) {
+      if (st) { total.converged = 0; *st = total; }
+      char buf[200];
+      snprintf(buf, sizeof buf, "BiCGStab stopped without convergence after %d iterations in %d passes (%d breakdowns), ||b - J x|| = %.3e, ||b|| = %.3e",
+               total.iterations, pass + 1, bad_passes, rn, bnorm);
+      return fail(GMPNP_ERR_LINEAR, buf);
+    }
     rhs_norm = rn;  // next pass solves J ddx = r (already in kr)
   }
   if (st) *st = total;
@@ -791,6 +827,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
+  HIP_TRY(s->krand.alloc(ndof));
   HIP_TRY(s->perm_dev.upload(t.perm));
   HIP_TRY(s->ticket.alloc(16 * 66));  // counter + 64 replicated flags, one cache line each
   HIP_TRY(s->part_a.alloc((size_t)2 * t.ntiles));  // (rhat,v) partials, then ||r||^2 partials

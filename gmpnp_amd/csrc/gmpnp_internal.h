@@ -39,6 +39,7 @@ struct KrylovScalars {
   double omega, beta; // written by coarse_a(k)
   double tol;        // absolute threshold on ||r||_2 (host)
   double rr;         // ||r||_2^2 seen by the last convergence test (B)
+  double rr0;        // ||r_0||_2^2 of this pass (host): divergence guard
   int32_t iters;     // completed iterations (B)
   int32_t it_cur;    // unused (the iteration index is a kernel argument); kept for the struct layout
   int32_t max_iters; // host

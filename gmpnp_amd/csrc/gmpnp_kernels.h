@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
   const int t = threadIdx.x, n = c.ncoarse;
   const int par = k & 1;
   const int done_flag = sc->done, max_iters = sc->max_iters;
-  const double rho_new = sc->rho[par], tol = sc->tol;
+  const double rho_new = sc->rho[par], tol = sc->tol, rr0 = sc->rr0;
   double acol[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) acol[f] = c.Aci[(size_t)min(t, n - 1) * n + g * NF + f];
@@ -1059,6 +1059,7 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
   int done = 0;
   if (!(rr == rr) || !(rv == rv)) done = 3;
   else if (sqrt(rr) <= tol) done = 1;
+  else if (rr > 1e10 * rr0) done = 3;  // residual 1e5 times its start: this pass is lost (BiCGStab spikes stay far below)
   else if (k >= max_iters) done = 2;
   else if (rv == 0.0 || rho_new == 0.0) done = 3;
   // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
@@ -1506,6 +1507,16 @@ __global__ void k_to_internal(double* __restrict__ dst, const double* __restrict
 __global__ void k_to_file(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int nf, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const int I = i / nf, f = i - I * nf; dst[(size_t)perm[I] * nf + f] = src[i]; }
+}
+
+// deterministic pseudo-random vector in [-1, 1) (shadow vector of a BiCGStab pass that follows a breakdown)
+__global__ void k_fill_hash(double* __restrict__ v, unsigned seed, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    v[i] = (double)h * (2.0 / 4294967296.0) - 1.0;
+  }
 }
 
 // warm start of the next Newton correction: x <- a x + b xp, xp <- old x  (x = dx_k, xp = dx_{k-1})
