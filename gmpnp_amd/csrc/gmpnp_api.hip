@@ -1141,11 +1141,16 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
       case 9: hipLaunchKernelGGL(k_stream_read, dim3(2048), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 10: hipLaunchKernelGGL(k_stream_read, dim3(512), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 11: hipLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
+      case 12: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_a<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
+                                                    (unsigned)s->t.nagg * (++s->fused_seq))); break;
+      case 13: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_b<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
+                                                    (unsigned)s->t.nagg * (++s->fused_seq))); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
     return r;
   };
-  if (kernel >= 4 && kernel <= 7) {  // Krylov kernels: a live (not finished) solve state
+  if (kernel == 12 || kernel == 13) { HIP_TRY(hipMemset(s->ticket.p, 0, 16 * 66 * sizeof(uint32_t))); s->fused_seq = 0; }
+  if ((kernel >= 4 && kernel <= 7) || kernel == 12 || kernel == 13) {  // Krylov kernels: a live (not finished) solve state
     KrylovScalars z{}; z.rho[0] = z.rho[1] = 1.0; z.alpha = 1.0; z.omega = 1.0; z.beta = 0.5; z.tol = 0.0; z.max_iters = 1 << 30;
     HIP_TRY(hipMemcpy(s->scal.p, &z, sizeof z, hipMemcpyHostToDevice));
   }

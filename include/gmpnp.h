@@ -209,7 +209,8 @@ int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t kind, const double* r_de
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
  * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming
- * read of the matrix buffer with 2048 / 512 / 8192 workgroups (bandwidth probes). */
+ * read of the matrix buffer with 2048 / 512 / 8192 workgroups (bandwidth probes), 12/13 = the two-launch form of the
+ * half-iterations (coarse workgroups inside the tile launch). */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
 /* Fused BiCGStab half-iteration launches (k_bicg_a / k_bicg_b: SpMV + vector updates) sampled with HIP events since
  * the last call (opts.profile_every): count, mean microseconds between the two events of a bracket. */

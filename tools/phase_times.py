@@ -24,7 +24,7 @@ dev.lib.gmpnp_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_voi
 dev.lib.gmpnp_debug_read(dev._h, 14, buf.ctypes.data, buf.size)
 st = buf[140 * 16:140 * 16 + 24].reshape(3, 8)
 t00 = st[:, 0].min()
-for name, row in zip(("first tile", "middle tile", "last tile"), st):
+for name, row in zip(("block 0", "middle block", "last block"), st):
     print("%-12s start %+7.2f us | phases (us from tile start): %s" % (name, (row[0] - t00) / 100.0, " ".join("%6.2f" % ((x - row[0]) / 100.0) for x in row[1:6])))
 occ = (ctypes.c_int * 4)()
 dev.lib.gmpnp_debug_occupancy(occ)
