@@ -18,3 +18,10 @@ EXTRA_EDL = {
     "edl50_default": (dict(), 3),
     "edl10_hohp": (dict(L_n=10e-6, voltage_multiplier=-2.5, H_OHP=0.5, H2_FE=0.4), 4),
 }
+
+# 1D reaction-diffusion driver (reference 1D/rxn_diff_planar.py) on the same backend
+EXTRA_RXN1D = {
+    "rxn1d_default": (dict(), 6),
+    "rxn1d_10um_05M": (dict(L_n=10e-6, concentration_KHCO3=0.5, H2_FE=0.4, current_OHP_ss=50.0), 5),
+}
+RXN_NEWTON = dict(maximum_iterations=100, relative_tolerance=1e-6, absolute_tolerance=1e-6)  # rxn_diff_planar.py:329-333

@@ -15,7 +15,7 @@ import scipy.sparse.linalg as spla
 
 import gmpnp_oracle as O
 from conftest import GOLDEN, random_state
-from golden_cases import EXTRA_EDL, EXTRA_PORE
+from golden_cases import EXTRA_EDL, EXTRA_PORE, EXTRA_RXN1D
 
 pytestmark = pytest.mark.gpu
 
@@ -346,6 +346,38 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     m1 = json.load(open(os.path.join(out1, "metadata.json")))
     assert {"eps_rel_OHP", "field_OHP", "pH_OHP", "CO2_OHP_frac", "mesh_number", "mesh_structure"} <= set(m1)
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA_RXN1D))
+def test_rxn_diff_1d_matches_golden(case, tmp_path, monkeypatch, gpu_lib):
+    """Reference 1D/rxn_diff_planar.py on the same kernels (valences 0, steric off, potential pinned by its Dirichlet
+    ends): Newton counts and states against the oracle's golden steps, then the driver's output files."""
+    import json
+    from gmpnp_amd.rxndiff1d import RxnDiffRun
+    kw, nsteps = EXTRA_RXN1D[case]
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    run = RxnDiffRun(num_steps=nsteps, **kw)
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        nv = run.mesh.num_vertices
+        for k in range(nsteps):
+            ref = g["states"][k].reshape(nv, 7)
+            assert relerr(run.history[k + 1].ravel(), ref[:, :5].ravel()) < 1e-8
+        full = run.sys.vertex_values()
+        assert np.allclose(full[:, 5], 1.0, rtol=0, atol=1e-12) and np.abs(full[:, 6]).max() < 1e-12  # cation placeholder, potential
+        monkeypatch.setenv("GMPNP_OUT", str(tmp_path))
+        out = run.write_outputs()
+    finally:
+        run.sys.close()
+    a = np.load(os.path.join(out, "arrays_unscaled.npz"))
+    assert a["OH"].shape == (nsteps + 1, nv) and a["coor_array"].shape == (nv, 1) and a["tau_array"].shape == (nsteps,)
+    s = np.load(os.path.join(out, "arrays_scaled.npz"))
+    assert {"x", "t_H", "c_H", "t_CO2", "c_CO2", "c_cat"} <= set(s.files)
+    assert np.allclose(s["c_cat"], s["c_HCO3"] + 2 * s["c_CO32"] + s["c_OH"] - s["c_H"])
+    meta = json.load(open(os.path.join(out, "metadata.json")))
+    assert {"concentration_KHCO3", "L_n", "bulk_pH", "time_constant", "total_sim_time", "time_step", "mesh_structure", "H2_FE",
+            "CO_FE", "current_OHP_ss", "pH_OHP", "pH_overpotential", "CO2_overpotential", "CO2_OHP_frac"} <= set(meta)
 
 
 def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):

@@ -102,3 +102,18 @@ def test_sechenov():
     assert rel(v, 0.95 * math.exp(lnK) * 1000 * 10 ** (-s) / b["CO2"]) < 1e-14
     assert v < pp.eq_conc_CO2_scaled  # salting out lowers the solubility
     assert co2_conc(298.15, 0.95, {}, {"CO2_0": 0.0, "CO2_T": 0.0}) == pytest.approx(0.95 * math.exp(lnK) * 1000)
+
+
+def test_rxn_diff_parameters_match_reference_formulas():
+    """Scalars of reference 1D/rxn_diff_planar.py:151-246 (0.1 M, 50 um: the same OHP fluxes as the EDL script)."""
+    from gmpnp_amd.rxndiff1d import rxn_diff_parameters
+    rp = rxn_diff_parameters()
+    assert rp.mesh_name == "1D_variable_50um_mesh_5990.xml.gz" and rp.num_steps == 500
+    assert abs(rp.scalars["J_OH"] / -13786.32 - 1) < 1e-6 and abs(rp.scalars["J_CO2"] / 0.0318624 - 1) < 1e-5
+    assert abs(rp.time_constant - (50e-6) ** 2 / rp.diff_coeff["CO32"]) < 1e-15
+    assert abs(rp.dt * rp.time_constant - 2.0e-2) < 1e-15 and abs(rp.model.inv_dt * rp.dt - 1) < 1e-14
+    m = rp.model
+    assert not m.steric and not m.z.any() and not m.a.any() and m.point_flux[1] == rp.scalars["J_OH"]
+    assert rp.species == ["H", "OH", "HCO3", "CO32", "CO2", "K"] and m.rc1[5].tolist() == [0.0] * 6  # cation: no source
+    with pytest.raises(UnboundLocalError):
+        rxn_diff_parameters(L_n=20e-6)  # no mesh for 20 um: the reference leaves mesh_number unbound

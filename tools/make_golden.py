@@ -23,8 +23,8 @@ from gmpnp_amd.model import default_quadrature
 G = os.path.join(ROOT, "tests", "golden")
 os.makedirs(G, exist_ok=True)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from golden_cases import EXTRA_PORE, EXTRA_EDL
-what = set(sys.argv[1:]) or ({"elements", "pore10", "pore50", "edl1", "edl50"} | set(EXTRA_PORE) | set(EXTRA_EDL))
+from golden_cases import EXTRA_PORE, EXTRA_EDL, EXTRA_RXN1D, RXN_NEWTON
+what = set(sys.argv[1:]) or ({"elements", "pore10", "pore50", "edl1", "edl50"} | set(EXTRA_PORE) | set(EXTRA_EDL) | set(EXTRA_RXN1D))
 
 
 def pad_res(res):
@@ -91,6 +91,19 @@ for key, (kw, steps) in EXTRA_EDL.items():
     mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
     prob = edl_problem(ep, mesh)
     out = O.edl_time_loop(ep, prob, steps, verbose=True)
+    np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
+                        residuals=pad_res(out["residuals"]))
+    print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
+
+for key, (kw, steps) in EXTRA_RXN1D.items():
+    if key not in what:
+        continue
+    t = time.time()
+    from gmpnp_amd.rxndiff1d import rxn_diff_parameters
+    rp = rxn_diff_parameters(**kw)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), rp.mesh_name))
+    prob = edl_problem(rp, mesh)
+    out = O.edl_time_loop(rp, prob, steps, newton_kwargs=RXN_NEWTON, verbose=True)
     np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
                         residuals=pad_res(out["residuals"]))
     print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
