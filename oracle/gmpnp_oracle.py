@@ -350,7 +350,7 @@ def project_gradient(coords, cells, f, sign=1.0):
 # ---------------------------------------------------------------------------------------------
 # Time loops (reference 3D:783-858 and 1D:633-796), oracle-side restatement for golden vectors
 # ---------------------------------------------------------------------------------------------
-def pore_time_loop(pp, prob, bnd, n_steps, newton_kwargs=None, verbose=False):
+def pore_time_loop(pp, prob, bnd, n_steps, newton_kwargs=None, verbose=False, cation_from_electroneutrality=False):
     """Backward-Euler loop of the 3D pore driver: Newton from the previous u (zeros at step 0, SURVEY §3.3
     item 6), median -> Sechenov -> new CO2 Dirichlet value (3D:817-838), u_n.assign(u) (3D:856).
     Returns dict(states (n_steps, ndof), newton_its, residuals, co2_bc)."""
@@ -364,7 +364,12 @@ def pore_time_loop(pp, prob, bnd, n_steps, newton_kwargs=None, verbose=False):
     for n in range(n_steps):
         u, st = newton_solve(prob, u, un, **kw)
         u2 = u.reshape(nv, nf)
-        co2 = pp.sechenov_co2_scaled(np.median(u2[:, 1]), np.median(u2[:, 2]), np.median(u2[:, 3]), np.median(u2[:, 7]))
+        med_cat = np.median(u2[:, 7])
+        if cation_from_electroneutrality:  # reaction-diffusion variant, reference 3D/rxn_diff_CO2ER_pore.py:564-568
+            b = pp.bulk_conc
+            med_cat = (np.median(u2[:, 2]) * b["HCO3"] + 2 * np.median(u2[:, 3]) * b["CO32"] + np.median(u2[:, 1]) * b["OH"]
+                       - np.median(u2[:, 0]) * b["H"]) / b[pp.cation]
+        co2 = pp.sechenov_co2_scaled(np.median(u2[:, 1]), np.median(u2[:, 2]), np.median(u2[:, 3]), med_cat)
         prob.bc_dofs, prob.bc_vals = pore_dirichlet(pp, bnd, co2)
         un = u.copy()
         out["states"].append(u.copy()); out["newton_its"].append(st.iterations)

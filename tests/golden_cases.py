@@ -25,3 +25,9 @@ EXTRA_RXN1D = {
     "rxn1d_10um_05M": (dict(L_n=10e-6, concentration_KHCO3=0.5, H2_FE=0.4, current_OHP_ss=50.0), 5),
 }
 RXN_NEWTON = dict(maximum_iterations=100, relative_tolerance=1e-6, absolute_tolerance=1e-6)  # rxn_diff_planar.py:329-333
+
+# 3D reaction-diffusion driver (reference 3D/rxn_diff_CO2ER_pore.py) on the same backend
+EXTRA_RXN3D = {
+    "rxn3d_pore10": (dict(concentration_elec=0.5, L=10e-9, R=5e-9), 3),
+    "rxn3d_pore10_1M": (dict(concentration_elec=1.0, L=10e-9, R=5e-9, H2_FE=0.2), 2),
+}

@@ -15,7 +15,7 @@ import scipy.sparse.linalg as spla
 
 import gmpnp_oracle as O
 from conftest import GOLDEN, random_state
-from golden_cases import EXTRA_EDL, EXTRA_PORE, EXTRA_RXN1D
+from golden_cases import EXTRA_EDL, EXTRA_PORE, EXTRA_RXN1D, EXTRA_RXN3D
 
 pytestmark = pytest.mark.gpu
 
@@ -378,6 +378,44 @@ def test_rxn_diff_1d_matches_golden(case, tmp_path, monkeypatch, gpu_lib):
     meta = json.load(open(os.path.join(out, "metadata.json")))
     assert {"concentration_KHCO3", "L_n", "bulk_pH", "time_constant", "total_sim_time", "time_step", "mesh_structure", "H2_FE",
             "CO_FE", "current_OHP_ss", "pH_OHP", "pH_overpotential", "CO2_overpotential", "CO2_OHP_frac"} <= set(meta)
+
+
+@pytest.mark.parametrize("case", sorted(EXTRA_RXN3D))
+def test_rxn_diff_3d_matches_golden(case, tmp_path, monkeypatch, gpu_lib):
+    """Reference 3D/rxn_diff_CO2ER_pore.py on the same kernels: Newton counts, states and the Sechenov CO2 value (cation
+    from electroneutrality) against the oracle's golden steps, then the driver's output files."""
+    import json
+    from gmpnp_amd.rxnpore3d import RxnPoreRun
+    kw, nsteps = EXTRA_RXN3D[case]
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    run = RxnPoreRun(num_steps=nsteps, **kw)
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:nsteps])
+        nv = run.mesh.num_vertices
+        for k in range(nsteps):
+            ref = g["states"][k].reshape(nv, 9)
+            assert relerr(run.history[k + 1].ravel(), ref[:, :7].ravel()) < 1e-8
+        assert abs(run.co2_bc - g["co2_bc"][nsteps - 1]) / run.co2_bc < 1e-9
+        full = run.sys.vertex_values()
+        # cation placeholder: 1 up to what the damped Newton (x0.1 per iteration from u = 0) leaves; potential: pinned
+        assert np.allclose(full[:, 7], 1.0, rtol=0, atol=1e-5) and np.abs(full[:, 8]).max() < 1e-10
+        monkeypatch.setenv("GMPNP_OUT", str(tmp_path))
+        out = run.write_outputs()
+    finally:
+        run.sys.close()
+    files = set(os.listdir(out))
+    assert {"arrays_unscaled.npz", "arrays_scaled.npz", "metadata.json", "solution_CO.pvd", "solution_H2.pvd", "solution_CO2.pvd",
+            "solution_OH.pvd", "solution_H.pvd", "solution_HCO3.pvd", "solution_CO32.pvd"} <= files
+    assert "solution_K.pvd" not in files and "solution_p.pvd" not in files
+    a = np.load(os.path.join(out, "arrays_unscaled.npz"))
+    assert a["H2"].shape == (nsteps + 1, nv) and a["coor"].shape == (nv, 3) and a["CO_grad"].shape == (3 * nv,)
+    assert "cat" not in a.files and "p" not in a.files
+    s = np.load(os.path.join(out, "arrays_scaled.npz"))
+    assert np.allclose(s["c_cat"], s["c_HCO3"] + 2 * s["c_CO32"] + s["c_OH"] - s["c_H"])
+    meta = json.load(open(os.path.join(out, "metadata.json")))
+    assert "voltage_multiplier" not in meta and {"eq_conc_CO", "eq_conc_H2", "current_planar", "CO2_min"} <= set(meta)
+    assert out.rstrip("/").endswith("L_10_R_5_P_g_1.0_D_eff_1.0_Re_1.0_rough_150.0")
 
 
 def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):

@@ -23,8 +23,8 @@ from gmpnp_amd.model import default_quadrature
 G = os.path.join(ROOT, "tests", "golden")
 os.makedirs(G, exist_ok=True)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from golden_cases import EXTRA_PORE, EXTRA_EDL, EXTRA_RXN1D, RXN_NEWTON
-what = set(sys.argv[1:]) or ({"elements", "pore10", "pore50", "edl1", "edl50"} | set(EXTRA_PORE) | set(EXTRA_EDL) | set(EXTRA_RXN1D))
+from golden_cases import EXTRA_PORE, EXTRA_EDL, EXTRA_RXN1D, EXTRA_RXN3D, RXN_NEWTON
+what = set(sys.argv[1:]) or ({"elements", "pore10", "pore50", "edl1", "edl50"} | set(EXTRA_PORE) | set(EXTRA_EDL) | set(EXTRA_RXN1D) | set(EXTRA_RXN3D))
 
 
 def pad_res(res):
@@ -106,4 +106,17 @@ for key, (kw, steps) in EXTRA_RXN1D.items():
     out = O.edl_time_loop(rp, prob, steps, newton_kwargs=RXN_NEWTON, verbose=True)
     np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
                         residuals=pad_res(out["residuals"]))
+    print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
+
+for key, (kw, steps) in EXTRA_RXN3D.items():
+    if key not in what:
+        continue
+    t = time.time()
+    from gmpnp_amd.rxnpore3d import rxn_pore_parameters
+    pp = rxn_pore_parameters(**kw)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    prob, bnd = pore_problem(pp, mesh)
+    out = O.pore_time_loop(pp, prob, bnd, steps, verbose=True, cation_from_electroneutrality=True)
+    np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
+                        residuals=pad_res(out["residuals"]), co2_bc=np.array(out["co2_bc"]))
     print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
