@@ -41,9 +41,32 @@ struct Lay {
 // ---------------------------------------------------------------------------------------------
 // deterministic workgroup reductions (256 threads = 4 waves)
 // ---------------------------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave, result in every lane.  DPP row shifts / row broadcasts (gfx9 data-parallel primitives:
+// plain VALU moves, no LDS crossbar) instead of six dependent ds_bpermute round trips: lanes shifted in from outside a
+// row read 0, after four shifts lane 15 of each row holds the row total, row_bcast:15 / :31 carry the totals across
+// rows into lane 63, which is read back into a scalar.  Fixed order: bitwise reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row: row total
+  v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63: wave total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+// Sum over aligned groups of 8 lanes; the total lands in the LAST lane of each group (lanes 7, 15, ... of the wave).
+__device__ inline double group8_sum_to_last(double v) {
+  v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4  -> lane 8k+7: lanes 8k .. 8k+7
   return v;
 }
 
@@ -762,8 +785,9 @@ struct AggSlotSums {
 #pragma unroll
       for (int u = 0; u < 4; ++u) v += (s0 + u * L < slots) ? w[u] : 0.0;
     }
-    v += __shfl_xor(v, 1, L); v += __shfl_xor(v, 2, L); v += __shfl_xor(v, 4, L);
-    if (l == 0 && combo < K * NF) lds[combo] = v;
+    static_assert(L == 8, "group8_sum_to_last");
+    v = group8_sum_to_last(v);
+    if (l == L - 1 && combo < K * NF) lds[combo] = v;
   }
 };
 
@@ -795,8 +819,8 @@ struct TileCoarse {
   __device__ inline void to_lds(const Ctx& c, double* ycl) {
     const int t = threadIdx.x, l = t & 7;
     double a = ((l < c.nagg) ? a0 : 0.0) + ((l + 8 < c.nagg) ? a1 : 0.0);
-    a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
-    if (l == 0 && (t >> 3) < ROWS) ycl[d] = a;
+    a = group8_sum_to_last(a);
+    if (l == 7 && (t >> 3) < ROWS) ycl[d] = a;
   }
 };
 
