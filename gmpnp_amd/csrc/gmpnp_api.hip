@@ -280,7 +280,7 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
   // own begin-to-end time, the quantity rocprofv3's kernel trace reports
   if (s->fused_half) {
     const dim3 fg(s->t.nagg + s->t.ntiles);
-    const unsigned target = (unsigned)s->t.nagg * (++s->fused_seq);
+    const unsigned target = (unsigned)(++s->fused_seq);
     if (WHICH == 0) {
       if (ev) hipExtLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
       else hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
@@ -1142,9 +1142,9 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
       case 10: hipLaunchKernelGGL(k_stream_read, dim3(512), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 11: hipLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 12: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_a<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
-                                                    (unsigned)s->t.nagg * (++s->fused_seq))); break;
+                                                    (unsigned)(++s->fused_seq))); break;
       case 13: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_b<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
-                                                    (unsigned)s->t.nagg * (++s->fused_seq))); break;
+                                                    (unsigned)(++s->fused_seq))); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
     return r;

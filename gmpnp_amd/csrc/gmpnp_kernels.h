@@ -717,8 +717,8 @@ struct PartialSums {
       for (int q = 0; q < K; ++q) r[q][u] = part[(size_t)q * stride + ic];
     }
   }
-  // lds: [ (kCoarseThreads/64) * K ]; one barrier inside
-  __device__ inline void reduce(double* lds, double (&out)[K], const double* __restrict__ part, int n, int stride) {
+  // lds: [ (kCoarseThreads/64) * K ].  reduce_partial: per-wave sums into LDS; the CALLER synchronises; reduce_final: totals.
+  __device__ inline void reduce_partial(double* lds, const double* __restrict__ part, int n, int stride) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double v[K];
 #pragma unroll
@@ -744,7 +744,8 @@ struct PartialSums {
     if (lane == 0)
 #pragma unroll
       for (int q = 0; q < K; ++q) lds[w * K + q] = v[q];
-    __syncthreads();
+  }
+  static __device__ inline void reduce_final(const double* lds, double (&out)[K]) {
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       double sacc = 0.0;
@@ -918,39 +919,37 @@ constexpr int kStagePre = 2;  // staged x entries per thread requested up front 
 // compiler sinks every request below this branch, i.e. behind the scalar round trip that fetches the flag.
 #define GMPNP_EXIT_IF_DONE(flag, keep_expr) do { if (flag) { if (c.ndof < 0) c.yc[0] = (keep_expr); return; } } while (0)
 // ---- in-launch hand-over from the coarse workgroups to the tile workgroups (fused launch form) ---------------------
-constexpr int kFlagCopies = 64;  // the "all coarse workgroups done" flag is replicated over 64 cache lines: 8 pollers per line
+// Hand-over flags: coarse workgroup g raises flag g (one cache line holds all of them) to the sequence number of the
+// launch; lane g of a tile workgroup's first wave polls flag g and the wave leaves the loop on a unanimous vote.  No
+// counter, no read-modify-write, no second hop: the consumers see a coarse workgroup's flag one store after its payload.
 template <bool FUSED>
-__device__ __forceinline__ void publish_ticket(const Ctx& c, unsigned target) {
+__device__ __forceinline__ void publish_ticket(const Ctx& c, unsigned seq, int g) {
   if (FUSED) {
     // No fences: the payload (yc, scalars) went out as agent-scope write-through stores (store_coherent); every thread
-    // drains its own stores, then one thread advances the counter.  A release fence would write back the whole L2 of
-    // the XCD and the consumers' acquire would invalidate theirs 66 times per launch (measured: +7 us per launch).
+    // drains its own stores, then one thread raises the flag.  A release fence would write back the whole L2 of the
+    // XCD and the consumers' acquire would invalidate theirs 66 times per launch (measured: +7 us per launch).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    __shared__ int last;
-    if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(c.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == target);
-    __syncthreads();
-    // the last coarse workgroup raises the replicated flags (launch sequence number = target / nagg is monotone)
-    if (last && threadIdx.x < kFlagCopies)
-      __hip_atomic_store(c.ticket + 16 * (1 + threadIdx.x), target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(c.ticket + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned target, int tile) {
+__device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
   __shared__ int ticket_ok;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool mine = lane < c.nagg;
     int ok = 1;
-    const unsigned* flag = c.ticket + 16 * (1 + (tile & (kFlagCopies - 1)));
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      // 2 s at 100 MHz.  The flag cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
+    while (true) {
+      const unsigned f = mine ? __hip_atomic_load(c.ticket + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+      if (__all(f >= seq)) break;
+      // 2 s at 100 MHz.  The flags cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
       // budget only has to outlast a time slice taken by another process sharing the GPU.  Ends the solve (later
       // launches exit at once).
-      if (wall_clock64() - t0 > 200000000ull) {
-        ok = 0; atomicOr(c.status, 8); c.scal->done = 3; break;
-      }
-      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 200000000ull) { ok = 0; if (lane == 0) { atomicOr(c.status, 8); c.scal->done = 3; } break; }
+      __builtin_amdgcn_s_sleep(1);
     }
-    ticket_ok = ok;
+    if (lane == 0) ticket_ok = ok;
   }
   __syncthreads();
   return ticket_ok != 0;
@@ -980,7 +979,6 @@ __device__ __forceinline__ double load_coherent(const int32_t* p) {
 template <int NF, bool FUSED>
 __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const int g, const unsigned target) {
   __shared__ double cs[4 * NF];
-  __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 4];
   KrylovScalars* sc = c.scal;
   const int t = threadIdx.x, n = c.ncoarse;
@@ -1015,47 +1013,40 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   if (first) rho_new = sc_rho1;  // the host puts (rhat, r_0) = ||b||^2 there
   else { alpha = sc_alpha; rho_old = par ? sc_rho0 : sc_rho1; }
   GMPNP_STAMP(1);
+  // ONE barrier: restriction sums of this aggregate and per-wave scalar sums go to LDS, then every thread finishes alone
   if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
+  if (!first) psum.reduce_partial(lred, c.part_b, c.ntiles, c.ntiles);
+  __syncthreads();
   GMPNP_STAMP(2);
   if (!first) {
     double tot[4];
-    psum.reduce(lred, tot, c.part_b, c.ntiles, c.ntiles);
+    PartialSums<4>::reduce_final(lred, tot);
     omega = tot[0] / tot[1];
     rho_new = tot[2] - omega * tot[3];
     beta = (rho_new / rho_old) * (alpha / omega);
-  } else {
-    __syncthreads();
   }
   GMPNP_STAMP(3);
   if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->omega, omega); store_coherent<FUSED>(&sc->beta, beta); sc->rho[par] = rho_new; }
-  if (!c.use_coarse) { publish_ticket<FUSED>(c, target); return; }
-  if (t < NF) {
-    const double vc = cs[t];
-    double rcn, pcn;
-    if (first) { rcn = vc; pcn = vc; }
-    else {
-      const double tc = cs[NF + t], rc_old = cs[2 * NF + t], pc_old = cs[3 * NF + t];
-      rcn = (rc_old - alpha * vc) - omega * tc;       // P^T r_k
-      pcn = rcn + beta * (pc_old - omega * vc);       // P^T p_k
-    }
-    pcs[t] = pcn;
-  }
-  __syncthreads();
+  if (!c.use_coarse) { publish_ticket<FUSED>(c, target, g); return; }
   GMPNP_STAMP(4);
   if (t < n) {
-    double acc = 0.0;
+    // yc = Aci[:, g-block] (P^T p_k)_g with P^T p_k = P^T r_k + beta (P^T p_{k-1} - omega P^T v), P^T r_k = P^T r_{k-1} -
+    // alpha P^T v - omega P^T t: the four block products do not wait for the scalars, only their combination does
+    double yv = 0.0, yt = 0.0, yr = 0.0, yp = 0.0;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
+    for (int f = 0; f < NF; ++f) {
+      yv += acol[f] * cs[f]; yt += acol[f] * cs[NF + f]; yr += acol[f] * cs[2 * NF + f]; yp += acol[f] * cs[3 * NF + f];
+    }
+    const double acc = first ? yv : ((yr - alpha * yv) - omega * yt) + beta * (yp - omega * yv);
     store_coherent<FUSED>(&c.yc[(size_t)g * n + t], acc);
   }
-  publish_ticket<FUSED>(c, target);
+  publish_ticket<FUSED>(c, target, g);
   GMPNP_STAMP(5);
 }
 
 template <int NF, bool FUSED>
 __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const int g, const unsigned target) {
   __shared__ double cs[2 * NF];
-  __shared__ double pcs[NF];
   __shared__ double lred[(kCoarseThreads / 64) * 2];
   KrylovScalars* sc = c.scal;
   const int t = threadIdx.x, n = c.ncoarse;
@@ -1077,8 +1068,10 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
     for (int f = 0; f < NF; ++f) keep += acol[f];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
+  psum.reduce_partial(lred, c.part_a, c.ntiles, c.ntiles);
+  __syncthreads();
   double tot[2];
-  psum.reduce(lred, tot, c.part_a, c.ntiles, c.ntiles);
+  PartialSums<2>::reduce_final(lred, tot);
   const double rv = tot[0], rr = tot[1];
   int done = 0;
   if (!(rr == rr) || !(rv == rv)) done = 3;
@@ -1089,16 +1082,14 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
   // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
   const double alpha = done ? 0.0 : rho_new / rv;
   if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->alpha, alpha); sc->rr = rr; store_coherent<FUSED>(&sc->done_next, (int32_t)done); }
-  if (done || !c.use_coarse) { publish_ticket<FUSED>(c, target); return; }
-  if (t < NF) pcs[t] = cs[NF + t] - alpha * cs[t];  // P^T s = P^T r_k - alpha P^T v_k
-  __syncthreads();
-  if (t < n) {
-    double acc = 0.0;
+  if (done || !c.use_coarse) { publish_ticket<FUSED>(c, target, g); return; }
+  if (t < n) {  // yc = Aci[:, g-block] (P^T s)_g, P^T s = P^T r_k - alpha P^T v_k
+    double yv = 0.0, yr = 0.0;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) acc += acol[f] * pcs[f];
-    store_coherent<FUSED>(&c.yc[(size_t)g * n + t], acc);
+    for (int f = 0; f < NF; ++f) { yv += acol[f] * cs[f]; yr += acol[f] * cs[NF + f]; }
+    store_coherent<FUSED>(&c.yc[(size_t)g * n + t], yr - alpha * yv);
   }
-  publish_ticket<FUSED>(c, target);
+  publish_ticket<FUSED>(c, target, g);
 }
 
 // ---- fused half-iterations ------------------------------------------------------------------------------------
@@ -1161,7 +1152,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {  // scalars and coarse products of THIS launch's coarse workgroups
-    if (!wait_ticket(c, target, tile)) return;
+    if (!wait_ticket(c, target)) return;
     omega = load_coherent(&sc->omega); beta = load_coherent(&sc->beta);
     tcs.template load_values<true>(c);
   }
@@ -1279,7 +1270,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {
-    if (!wait_ticket(c, target, tile)) return;
+    if (!wait_ticket(c, target)) return;
     dn = (int)load_coherent(&sc->done_next); alpha = load_coherent(&sc->alpha);
     if (!dn) tcs.template load_values<true>(c);
   }
@@ -1347,9 +1338,9 @@ __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const in
 
 // ... or two: the nagg coarse workgroups ride in front of the tile workgroups of the same launch.  A tile workgroup
 // requests everything that does not depend on the coarse result (indices, matrix slice, operand vectors), then waits
-// for the ticket counter to reach `target` (= nagg x launches so far in this solve) before it reads the scalars and
+// for the flags of all coarse workgroups to reach `target` (= launches so far in this solve) before it reads the scalars and
 // the coarse products.  Coarse workgroups have the lowest block indices (dispatched first) and wait for nobody, so
-// the counter always arrives; the wait is bounded by a wall-clock budget all the same (status bit 8).
+// the flags always arrive; the wait is bounded by a wall-clock budget all the same (status bit 8).
 static_assert(kCoarseThreads == kKrylovThreads, "coarse and tile workgroups share a launch");
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_a(const Ctx c, const int k, const unsigned target) {
