@@ -29,7 +29,10 @@ constexpr int kSlicesPerTile = GMPNP_SLICES_PER_TILE;    // SELL slices (of 7 or
 constexpr int kTileAggs = 6;         // coarse aggregates the rows of one tile may prolong from
 constexpr int kTileCols = 224;       // distinct column nodes a tile may reference (x staged in LDS: kTileCols*NF doubles)
 constexpr int kSlicePad = 16;       // per-(slice,kpos) column-index record length (>= rows per slice: 7 or 9)
-constexpr int kRowPad = GMPNP_KRYLOV_WAVES * GMPNP_ROW_PRELOAD;  // block positions of zero padding behind the last slice
+#ifndef GMPNP_ROW_PRELOAD_B
+#define GMPNP_ROW_PRELOAD_B 2  // B half of the two-launch form: its register budget allows a second block position up front
+#endif
+constexpr int kRowPad = GMPNP_KRYLOV_WAVES * (GMPNP_ROW_PRELOAD_B > GMPNP_ROW_PRELOAD ? GMPNP_ROW_PRELOAD_B : GMPNP_ROW_PRELOAD);  // block positions of zero padding behind the last slice
 
 // Device scalars of one BiCGStab solve.  Each field has ONE writer kernel and is read only by later launches
 // (fields written by kernel A are read by B and vice versa; rho is double-buffered by iteration parity).

@@ -860,9 +860,9 @@ struct CoarseRows {
 // Matrix part shared by the tile kernels: the wave's first PRE blocks are requested up front, x comes from LDS.
 // The preload is unconditional (vals / sell_lcol carry kRowPad block positions of zero padding behind the last
 // slice, positions past a short slice's end just read into the next slice) and masked afterwards.
-template <int NF>
+template <int NF, int PRE_ = GMPNP_ROW_PRELOAD>
 struct TileRows {
-  static constexpr int PRE = GMPNP_ROW_PRELOAD;
+  static constexpr int PRE = PRE_;
   double av[PRE][NF];
   int lc[PRE];
   int Iloc, i, cb, mx, w, row;
@@ -1149,7 +1149,9 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
 #pragma unroll
     for (int u = 0; u < kStagePre; ++u) keep += (st_s[u] + st_t[u]) + (st_p[u] + st_v[u]);
 #pragma unroll
-    for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
+    for (int u = 0; u < decltype(rows)::PRE; ++u)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) keep += rows.av[u][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {  // scalars and coarse products of THIS launch's coarse workgroups
     if (!wait_ticket(c, target)) return;
@@ -1250,7 +1252,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
   TileCoarse<NF> tcs;
   tcs.load_index(c, tile);
   if (!FUSED) tcs.template load_values<false>(c);
-  TileRows<NF> rows;
+  TileRows<NF, (FUSED ? GMPNP_ROW_PRELOAD_B : GMPNP_ROW_PRELOAD)> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
   double st_r[kStagePre], st_v[kStagePre];
@@ -1267,7 +1269,9 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
     for (int u = 0; u < kStagePre; ++u) keep += st_r[u] + st_v[u];
 #pragma unroll
-    for (int j = 0; j < NF; ++j) keep += rows.av[0][j];
+    for (int u = 0; u < decltype(rows)::PRE; ++u)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) keep += rows.av[u][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {
     if (!wait_ticket(c, target)) return;
