@@ -28,7 +28,7 @@ EXPORTS = [
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
-    "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
+    "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library(path: str = None):
     lib.gmpnp_linear_solve.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), c_int32, c_double, c_double,
                                        c_int32, POINTER(CLinearStats)]
     lib.gmpnp_precond_apply.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
+    lib.gmpnp_set_supg.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32)]
     lib.gmpnp_set_state_device.argtypes = [c_void_p, c_void_p, c_void_p]      # raw device addresses (tensor.data_ptr())
     lib.gmpnp_assemble_device.argtypes = [c_void_p, c_int32, c_void_p, POINTER(c_double)]
     lib.gmpnp_spmv_device.argtypes = [c_void_p, c_void_p, c_void_p]
@@ -334,6 +335,16 @@ class DeviceSolver:
         z = np.empty(self.ndof)
         self._check(self.lib.gmpnp_precond_apply(self._h, linear_solver, _dptr(r), _dptr(z)))
         return z
+
+    def set_supg(self, rho=None, w_index=None):
+        """Nodal SUPG parameters (nv, ns) of the PNP stabilisation (reference 1D:597-722), or None to switch it off."""
+        if rho is None:
+            self._check(self.lib.gmpnp_set_supg(self._h, None, None))
+            return
+        rho = np.ascontiguousarray(rho, dtype=np.float64).reshape(-1)
+        assert rho.size == (self.ndof // self.nf) * (self.nf - 1)
+        w = None if w_index is None else np.ascontiguousarray(w_index, dtype=np.int32)
+        self._check(self.lib.gmpnp_set_supg(self._h, _dptr(rho), None if w is None else _iptr(w)))
 
     # ---- device-pointer variants: arguments are device addresses (e.g. ``torch.Tensor.data_ptr()`` of contiguous fp64
     # tensors of length ndof on this handle's GPU, file vertex order); the caller synchronises its own stream first ----

@@ -94,6 +94,7 @@ struct gmpnp_solver {
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
   int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
   DevBuf<uint32_t> ticket;
+  DevBuf<double> supg_rho;  // [nv][ns] internal order
   DevBuf<int32_t> perm_dev;  // file vertex of each internal node (device-pointer entry points)
   bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); GMPNP_FUSED_HALF=1
   unsigned fused_seq = 0;   // fused launches so far in the current solve
@@ -897,6 +898,31 @@ int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model) {
   HIP_TRY(hipMemcpy(s->d_model.p, &s->model, sizeof(gmpnp_model_t), hipMemcpyHostToDevice));
   s->jacobian_valid = false; s->precond_valid = false;
   return rebuild_boundary(s);
+}
+
+int gmpnp_set_supg(gmpnp_solver* s, const double* rho, const int32_t* w_index) {
+  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->jacobian_valid = false;
+  if (!rho) { s->c.supg_rho = nullptr; return GMPNP_OK; }
+  if (s->dim != 1) return fail(GMPNP_ERR_INVALID, "SUPG stabilisation exists for 1D meshes only (reference 1D:597-722)");
+  const int ns = s->nf - 1, nv = s->t.nv;
+  std::vector<double> tmp((size_t)nv * ns);
+  for (int I = 0; I < nv; ++I)
+    for (int j = 0; j < ns; ++j) {
+      const double v = rho[(size_t)s->t.perm[I] * ns + j];
+      if (!(v == v) || v < 0.0) return fail(GMPNP_ERR_INVALID, "SUPG parameters must be finite and non-negative");
+      tmp[(size_t)I * ns + j] = v;
+    }
+  HIP_TRY(s->supg_rho.upload(tmp));
+  s->c.supg_rho = s->supg_rho.p;
+  for (int j = 0; j < GMPNP_MAX_SPECIES; ++j) {
+    const int w = (w_index && j < ns) ? w_index[j] : j;
+    if (j < ns && (w < 0 || w >= ns)) return fail(GMPNP_ERR_INVALID, "SUPG gradient index out of range");
+    s->c.supg_w[j] = w;
+  }
+  return GMPNP_OK;
 }
 
 int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values) {

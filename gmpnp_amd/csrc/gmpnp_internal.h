@@ -152,6 +152,8 @@ struct Ctx {
   KrylovScalars* scal;
   int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse, bit 3: hand-over timeout)
   uint32_t* ticket; // fused launch form: coarse workgroups finished so far in this solve
+  const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722
+  int32_t supg_w[GMPNP_MAX_SPECIES];  // species whose gradient enters species i's strong residual (identity except Q7)
 };
 
 // Host-side topology/layout tables (internal vertex order).

@@ -32,7 +32,8 @@ struct Lay {
   static constexpr int O_B = O_IJ + NS;          // [NN] int beta phi_b
   static constexpr int O_C = O_B + NN;           // [NS][NN] int u_i beta^2 phi_b
   static constexpr int O_D = O_C + NS * NN;       // [MAX_BILINEAR][2][NN][NN] d(int u_x u_y phi_a)/d u_{x,b} and /d u_{y,b}
-  static constexpr int EJ_STRIDE = O_D + GMPNP_MAX_BILINEAR * 2 * NN * NN;
+  static constexpr int O_S = O_D + GMPNP_MAX_BILINEAR * 2 * NN * NN;  // 1D only: [NN][NF][NN][NF] SUPG element matrix (PNP + stabilisation)
+  static constexpr int EJ_STRIDE = O_S + (DIM == 1 ? NN * NF * NN * NF : 0);
   static constexpr int EF_STRIDE = NN * NF;
   static constexpr double MDEN = 1.0 / ((DIM + 1) * (DIM + 2));  // M_ab = |K| (1+delta_ab) MDEN
   static constexpr double KAPPA = (DIM == 3) ? 1.0 / 120.0 : 1.0 / 24.0;  // d!/(d+3)!
@@ -305,6 +306,108 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
     }
     ef[a * NF + NS] = fp;
   }
+  // ---- SUPG stabilisation of the PNP model (reference 1D:687-714; 1D meshes only) -----------------------------------
+  //   F_stab = - sum_i rho_i z_i [ (u_i - u_i^n)/(dt L_D) + z_i grad(w_i).grad(p) + R_i ] grad(p).grad(v_i) dx
+  // rho_i: nodal (P1), w_i = u_i except the reference's OH term, which takes grad(u_H) (c.supg_w); R_i the
+  // production rate (the tables hold -R_i).  Degree <= 3 on a P1 element: closed form.  The element matrix of these
+  // terms is dense in (species, potential) and is stored whole (196 doubles) for the Jacobian gather.
+  if constexpr (DIM == 1) {
+    if (c.supg_rho) {
+      double* js = nullptr;
+      if constexpr (WANT_J) {
+        js = c.EJ + (size_t)e * L::EJ_STRIDE + L::O_S;
+        for (int q = 0; q < NN * NF * NN * NF; ++q) js[q] = 0.0;
+      }
+      for (int i = 0; i < NS; ++i) {
+        const double zi = m.z[i];
+        if (zi == 0.0) continue;
+        const int wi = c.supg_w[i];
+        double rho[NN], du[NN], uw[NN];
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+          rho[a] = c.supg_rho[(size_t)nd[a] * NS + i];
+          du[a] = U[a][i] - c.un[(size_t)nd[a] * NF + i];
+          double v = 0.0;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) v = (j == wi) ? U[a][j] : v;
+          uw[a] = v;
+        }
+        double rsum = 0.0, gradw = 0.0;
+#pragma unroll
+        for (int a = 0; a < NN; ++a) { rsum += rho[a]; gradw += uw[a] * g[a][0]; }
+        const double rbar = rsum * (1.0 / NN);
+        double rM[NN];
+#pragma unroll
+        for (int b = 0; b < NN; ++b) rM[b] = vol * L::MDEN * (rsum + rho[b]);
+        double S = zi * (gradw * gradp[0]) * vol * rbar - m.rc0[i] * vol * rbar;
+#pragma unroll
+        for (int b = 0; b < NN; ++b) S += m.inv_dt * rM[b] * du[b];
+        for (int j = 0; j < NS; ++j) {
+          const double c1 = m.rc1[i][j];
+          if (c1 != 0.0)
+#pragma unroll
+            for (int b = 0; b < NN; ++b) S -= c1 * rM[b] * U[b][j];
+        }
+        // bilinear terms: sum_abc rho_a x_b y_c T_abc |K|, T_abc = kappa (6 | 2 | 1 for three | two | no equal indices)
+        double dSx[GMPNP_MAX_BILINEAR][NN], dSy[GMPNP_MAX_BILINEAR][NN];
+        for (int t = 0; t < m.n_bilinear; ++t) {
+          const double c2 = m.rc2[i][t];
+          const int bj = m.bil_j[t], bk = m.bil_k[t];
+          double xs[NN], ys[NN];
+#pragma unroll
+          for (int a = 0; a < NN; ++a) {
+            double xv = 0.0, yv = 0.0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { xv = (j == bj) ? U[a][j] : xv; yv = (j == bk) ? U[a][j] : yv; }
+            xs[a] = xv; ys[a] = yv;
+          }
+          double tot = 0.0;
+#pragma unroll
+          for (int b = 0; b < NN; ++b) { dSx[t][b] = 0.0; dSy[t][b] = 0.0; }
+#pragma unroll
+          for (int a = 0; a < NN; ++a)
+#pragma unroll
+            for (int b = 0; b < NN; ++b)
+#pragma unroll
+              for (int cc = 0; cc < NN; ++cc) {
+                const double T = vol * L::KAPPA * ((a == b && b == cc) ? 6.0 : ((a == b || b == cc || a == cc) ? 2.0 : 1.0));
+                tot += rho[a] * xs[b] * ys[cc] * T;
+                dSx[t][b] += rho[a] * ys[cc] * T;   // d/d x_b
+                dSy[t][cc] += rho[a] * xs[b] * T;   // d/d y_c
+              }
+          S -= c2 * tot;
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) ef[a * NF + i] += -zi * gp[a] * S;
+        if constexpr (WANT_J) {
+#pragma unroll
+          for (int b = 0; b < NN; ++b) {
+            double dS[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) dS[j] = 0.0;
+            for (int j = 0; j < NS; ++j) {
+              double v = -m.rc1[i][j] * rM[b];
+              if (j == i) v += m.inv_dt * rM[b];
+              if (j == wi) v += zi * gp[b] * vol * rbar;
+              for (int t = 0; t < m.n_bilinear; ++t) {
+                const double c2 = m.rc2[i][t];
+                if (j == m.bil_j[t]) v -= c2 * dSx[t][b];
+                if (j == m.bil_k[t]) v -= c2 * dSy[t][b];
+              }
+              dS[j] = v;
+            }
+            const double dSp = zi * (gradw * g[b][0]) * vol * rbar;
+#pragma unroll
+            for (int a = 0; a < NN; ++a) {
+              double* row = js + ((size_t)(a * NF + i) * NN + b) * NF;
+              for (int j = 0; j < NS; ++j) row[j] = -zi * gp[a] * dS[j];
+              row[NS] = -zi * (gg[a][b] * S + gp[a] * dSp);
+            }
+          }
+        }
+      }
+    }
+  }
   if constexpr (WANT_J) {
     double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
     ej[L::O_VOL] = vol;
@@ -442,6 +545,17 @@ __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) pk[u] = pkn[u];
+  }
+  if constexpr (DIM == 1) {
+    if (c.supg_rho) {  // dense SUPG element matrices (PNP + stabilisation), added after the regular terms in element order
+      for (int q = qb; q < qe; ++q) {
+        const int pk = c.contrib[q];
+        const int e = pk >> 4, a = (pk >> 2) & 3, b = pk & 3;
+        const double* row = c.EJ + (size_t)e * L::EJ_STRIDE + L::O_S + ((size_t)(a * NF + i) * NN + b) * NF;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[j] += row[j];
+      }
+    }
   }
   if (bc) {  // [3P] DirichletBC.apply(A): identity row
 #pragma unroll

@@ -21,7 +21,7 @@ import numpy as np
 from .mesh import read_dolfin_xml, resolve_mesh_path
 from .params import edl_parameters, utilities_dir
 from .problem import edl_problem
-from .solver import GMPNPSystem, project_gradient
+from .solver import GMPNPSystem, project_gradient, supg_parameters
 
 SOLVER_PARAMETERS = {  # reference 1D:357-364
     "nonlinear_solver": "newton",
@@ -45,12 +45,10 @@ class EDLRun:
         self.kwargs = kwargs
         self.ep = edl_parameters(**kwargs)
         ep = self.ep
-        if kwargs.get("stabilization", "N") == "Y":
-            if ep.model_name == "PNP":
-                raise NotImplementedError("PNP SUPG stabilisation (reference 1D:597-722) is not in the MI355X backend")
-            self.warn_stab = True
-        else:
-            self.warn_stab = False
+        stab = kwargs.get("stabilization", "N") == "Y"
+        self.supg = stab and ep.model_name == "PNP"        # reference 1D:687-722
+        self.warn_stab = stab and ep.model_name != "PNP"   # "Warning:stabilization not implemented for MPNP!", 1D:724-727
+        self.h_vertex = None
         self.mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
         self.problem = edl_problem(ep, self.mesh)
         self.model = copy.deepcopy(self.problem.model)
@@ -80,6 +78,12 @@ class EDLRun:
         self.t += self.dt
         if self.warn_stab and verbose:
             print("Warning:stabilization not implemented for MPNP!")
+        if self.supg:  # rho_i from the previous step's potential (u_n), OH's strong residual with grad(u_H)
+            rho, self.h_vertex = supg_parameters(self.mesh.coords, self.mesh.cells, self.model.z, self.history[-1][:, 6],
+                                                 self.h_vertex)
+            w = np.arange(6, dtype=np.int32)
+            w[ep.species.index("OH")] = ep.species.index("H")
+            self.sys.dev.set_supg(rho, w)
         st = self.sys.solve(self.solver_parameters)
         vals = self.sys.vertex_values()
         self.history.append(vals)

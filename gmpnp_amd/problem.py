@@ -27,6 +27,11 @@ class Problem:
     point_vertices: np.ndarray = None  # 1D: vertices carrying the point fluxes (the OHP vertex)
     bc_dofs: np.ndarray = None  # Dirichlet dofs (unique, sorted; the last DirichletBC in the list wins)
     bc_vals: np.ndarray = None
+    # SUPG stabilisation of the PNP model (reference 1D:597-722): nodal rho_i (nv, ns), zero where a species is not
+    # stabilised, and the species whose gradient enters species i's strong residual (identity except the reference's
+    # OH term, which takes grad(u_H): SURVEY Q7).  None = no stabilisation.
+    supg_rho: np.ndarray = None
+    supg_w: np.ndarray = None
 
     def __post_init__(self):
         d = self.coords.shape[1]

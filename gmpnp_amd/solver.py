@@ -92,3 +92,49 @@ def project_gradient(coords, cells, f, sign=1.0):
         rhs = np.bincount(cells.ravel(), weights=np.repeat(sign * gradf[:, k] * vol / nn, nn), minlength=nv)
         out[:, k] = lu.solve(rhs)
     return out
+
+
+def project_cellwise(coords, cells, values):
+    """``project(f, Y).compute_vertex_values()`` of a cell-wise constant f onto P1 (reference 1D:599
+    ``project(CellDiameter(mesh))``, 1D:651-653 ``project(sqrt(inner(grad(u_np), grad(u_np))))``): consistent-mass L2
+    projection, host SciPy like the reference's own per-step NumPy post-processing around its solve."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    nv, d = coords.shape
+    nn = d + 1
+    X = coords[cells]
+    if d == 1:
+        vol = np.abs(X[:, 1, 0] - X[:, 0, 0])
+    else:
+        vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
+    M = (np.ones((nn, nn)) + np.eye(nn)) / ((d + 1) * (d + 2))
+    rows = np.repeat(cells, nn, axis=1).ravel()
+    cols = np.tile(cells, (1, nn)).ravel()
+    Mg = sp.coo_matrix(((M[None] * vol[:, None, None]).ravel(), (rows, cols)), shape=(nv, nv)).tocsc()
+    rhs = np.bincount(cells.ravel(), weights=np.repeat(values * vol / nn, nn), minlength=nv)
+    return spla.splu(Mg).solve(rhs)
+
+
+def supg_parameters(coords, cells, z, p_prev, h_vertex=None, fact=1.0, tol=1.0e-14):
+    """Nodal SUPG parameters of the PNP stabilisation, reference 1D:597-670 (1D meshes): Pe_i = fact h |grad p| |z_i| / 2
+    at the vertices (h = projected cell diameter, |grad p| = projected gradient norm of the PREVIOUS step's potential);
+    rho_i = fact h / (2 |z_i| |grad p|) where Pe_i > 1 + tol, else fact^2 h^2 / 4; 0 for uncharged species.
+    Returns (rho (nv, ns), h_vertex)."""
+    assert coords.shape[1] == 1, "the reference stabilises the 1D script only"
+    X = coords[cells]
+    length = X[:, 1, 0] - X[:, 0, 0]
+    if h_vertex is None:
+        h_vertex = project_cellwise(coords, cells, np.abs(length))
+    gradp = (p_prev[cells[:, 1]] - p_prev[cells[:, 0]]) / length
+    norm = project_cellwise(coords, cells, np.abs(gradp))
+    z = np.asarray(z, dtype=float)
+    rho = np.zeros((coords.shape[0], len(z)))
+    rho_small = fact ** 2 * h_vertex ** 2 / 4
+    for i, zi in enumerate(z):
+        if zi == 0:
+            continue
+        Pe = fact * h_vertex * norm * abs(zi) / 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rho_large = fact * h_vertex / (2 * abs(zi) * norm)
+        rho[:, i] = np.where(Pe > 1.0 + tol, rho_large, rho_small)
+    return rho, h_vertex

@@ -155,6 +155,13 @@ void gmpnp_destroy(gmpnp_solver* s);
 /* Re-upload constants (Constant(...) objects rebuilt between steps: del_t 1D:639-642 (Q2), J_OH/J_H 1D:789-793). */
 int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model);
 
+/* SUPG stabilisation of the PNP model, reference 1D/MPNP_CO2ER_EDL.py:597-722 (--model PNP --stabilization Y; 1D
+ * meshes only): F gets  - sum_i rho_i z_i [ (u_i - u_i^n)/(dt L_D) + z_i grad(w_i).grad(p) + R_i ] grad(p).grad(v_i) dx
+ * with the P1 field rho_i given by its vertex values rho[vertex*n_species + i] (0 = species not stabilised; the
+ * reference recomputes them every time step from the previous potential, 1D:650-685) and w_i = u_{w_index[i]} (NULL =
+ * identity; the reference's OH term takes grad(u_H)). rho = NULL switches the terms off. */
+int gmpnp_set_supg(gmpnp_solver* s, const double* rho, const int32_t* w_index);
+
 /* bcs list after DOLFIN's in-order application (later wins): unique dofs + values (3D:460-467,835-838; 1D:350-355). */
 int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values);
 

@@ -164,6 +164,61 @@ def element_residual_jacobian(model: Model, quad: Quadrature, X, U, Un, want_jac
     return Fe, Je
 
 
+def supg_terms(model: Model, X, U, Un, rho_e, w_index, want_jacobian=True):
+    """SUPG stabilisation of the PNP model, reference 1D/MPNP_CO2ER_EDL.py:687-714:
+
+        F_stab = - sum_i  rho_i z_i [ (u_i - u_i^n)/(dt L_D) + z_i grad(w_i).grad(p) + R_i ] grad(p).grad(v_i) dx
+
+    with P1 nodal rho_i (zero for unstabilised species), w_i = u_i except w_OH = u_H (the reference's typo),
+    and R_i the production rate (the model tables hold -R_i).  Everything is polynomial of degree <= 3 on a P1 element:
+    closed form, exact like the reference's degree-3 rule.  Returns the ADDITIONS (Fe, Je) to the element vectors."""
+    ns, nf = model.n_species, model.n_fields
+    nc, nn, d = X.shape
+    vol, g = _geometry(X)
+    i1, M, T3 = _mass_tables(d)
+    u, p, un = U[:, :, :ns], U[:, :, ns], Un[:, :, :ns]
+    z = np.asarray(model.z)
+    Mab = M[None] * vol[:, None, None]
+    gradp = np.einsum("ea,ead->ed", p, g)
+    gp_a = np.einsum("ed,ead->ea", gradp, g)                 # grad p . grad phi_a
+    gg = np.einsum("ead,ebd->eab", g, g)
+    w = u[:, :, np.asarray(w_index)]                          # (nc,nn,ns)
+    gradw = np.einsum("eai,ead->eid", w, g)                   # (nc,ns,d)
+    wp = np.einsum("eid,ed->ei", gradw, gradp)                # grad w_i . grad p
+    gw_b = np.einsum("eid,ebd->eib", gradw, g)                # grad w_i . grad phi_b
+    rbar = rho_e.mean(axis=1)                                 # (nc,ns)
+    rM = np.einsum("eai,eab->eib", rho_e, Mab)                # sum_a rho_ia M_ab
+    # S_i = int rho_i [ ... ]
+    S = model.inv_dt * np.einsum("eib,ebi->ei", rM, u - un)
+    S += z[None, :] * wp * vol[:, None] * rbar
+    S -= model.rc0[None, :] * vol[:, None] * rbar
+    S -= np.einsum("ij,eib,ebj->ei", model.rc1, rM, u)
+    rT = np.einsum("eai,abc->eibc", rho_e, T3) * vol[:, None, None, None]   # sum_a rho_ia T_abc |K|
+    for t, (bj, bk) in enumerate(model.bil):
+        S -= model.rc2[None, :, t] * np.einsum("eibc,eb,ec->ei", rT, u[:, :, bj], u[:, :, bk])
+    Fe = np.zeros((nc, nn, nf))
+    Fe[:, :, :ns] = -z[None, None, :] * gp_a[:, :, None] * S[:, None, :]
+    if not want_jacobian:
+        return Fe, None
+    Je = np.zeros((nc, nn, nf, nn, nf))
+    for i in range(ns):
+        if z[i] == 0.0:
+            continue
+        dS_du = np.zeros((nc, nn, ns))                        # [b, j]
+        dS_du[:, :, i] += model.inv_dt * rM[:, i, :]
+        dS_du[:, :, w_index[i]] += z[i] * gp_a * (vol * rbar[:, i])[:, None]
+        dS_du -= rM[:, i, :, None] * model.rc1[i][None, None, :]
+        for t, (bj, bk) in enumerate(model.bil):
+            c = model.rc2[i, t]
+            if c != 0.0:
+                dS_du[:, :, bj] -= c * np.einsum("ebc,ec->eb", rT[:, i], u[:, :, bk])
+                dS_du[:, :, bk] -= c * np.einsum("ecb,ec->eb", rT[:, i], u[:, :, bj])
+        dS_dp = z[i] * gw_b[:, i, :] * (vol * rbar[:, i])[:, None]   # [b]
+        Je[:, :, i, :, :ns] += -z[i] * gp_a[:, :, None, None] * dS_du[:, None, :, :]
+        Je[:, :, i, :, ns] += -z[i] * (gg * S[:, i, None, None] + gp_a[:, :, None] * dS_dp[:, None, :])
+    return Fe, Je
+
+
 # ---------------------------------------------------------------------------------------------
 # Exterior-facet / point integrals
 # ---------------------------------------------------------------------------------------------
@@ -238,6 +293,12 @@ def assemble(prob: Problem, u, un, want_jacobian=True, apply_bc=True):
     cells = prob.cells
     Fe, Je = element_residual_jacobian(prob.model, prob.quad, prob.coords[cells], u2d[cells], un2d[cells],
                                        want_jacobian)
+    if getattr(prob, "supg_rho", None) is not None:
+        Fs, Js = supg_terms(prob.model, prob.coords[cells], u2d[cells], un2d[cells], prob.supg_rho[cells], prob.supg_w,
+                            want_jacobian)
+        Fe = Fe + Fs
+        if want_jacobian:
+            Je = Je + Js
     nn = cells.shape[1]
     dofs = (cells[:, :, None] * nf + np.arange(nf)[None, None, :]).reshape(len(cells), nn * nf)
     F = np.bincount(dofs.ravel(), weights=Fe.reshape(len(cells), -1).ravel(), minlength=prob.ndof)
@@ -347,6 +408,46 @@ def project_gradient(coords, cells, f, sign=1.0):
     return out
 
 
+def project_cellwise(coords, cells, values):
+    """``project(f, Y).compute_vertex_values()`` of a cell-wise constant f onto P1: consistent-mass L2 projection
+    (reference 1D:599 ``project(CellDiameter(mesh))``, 1D:651-653 ``project(sqrt(inner(grad(u_np), grad(u_np))))``)."""
+    nv, d = coords.shape
+    vol, _ = _geometry(coords[cells])
+    i1, M, _ = _mass_tables(d)
+    nn = d + 1
+    rows = np.repeat(cells, nn, axis=1).ravel()
+    cols = np.tile(cells, (1, nn)).ravel()
+    Mg = sp.coo_matrix(((M[None] * vol[:, None, None]).ravel(), (rows, cols)), shape=(nv, nv)).tocsc()
+    rhs = np.bincount(cells.ravel(), weights=np.repeat(values * vol * i1, nn), minlength=nv)
+    return spla.splu(Mg).solve(rhs)
+
+
+def supg_rho(coords, cells, z, p_prev, h_vertex=None, fact=1.0, tol=1e-14):
+    """Nodal SUPG parameters of reference 1D:597-670: Pe_i = fact h |grad p| |z_i| / 2 at the vertices (h and |grad p|
+    projected onto P1); rho_i = fact h / (2 |z_i| |grad p|) where Pe_i > 1, else fact^2 h^2 / 4; 0 for z_i = 0.
+    Returns (rho (nv, ns), h_vertex)."""
+    X = coords[cells]
+    if h_vertex is None:
+        diam = np.abs(X[:, 1, 0] - X[:, 0, 0]) if coords.shape[1] == 1 else None
+        if diam is None:
+            raise NotImplementedError("CellDiameter in 3D")
+        h_vertex = project_cellwise(coords, cells, diam)
+    _, g = _geometry(X)
+    gradp = np.einsum("ea,ead->ed", p_prev[cells], g)
+    norm = project_cellwise(coords, cells, np.sqrt((gradp ** 2).sum(axis=1)))
+    z = np.asarray(z, dtype=float)
+    rho = np.zeros((coords.shape[0], len(z)))
+    rho_small = fact ** 2 * h_vertex ** 2 / 4
+    for i, zi in enumerate(z):
+        if zi == 0:
+            continue
+        Pe = fact * h_vertex * norm * abs(zi) / 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rho_large = fact * h_vertex / (2 * abs(zi) * norm)
+        rho[:, i] = np.where(Pe > 1.0 + tol, rho_large, rho_small)
+    return rho, h_vertex
+
+
 # ---------------------------------------------------------------------------------------------
 # Time loops (reference 3D:783-858 and 1D:633-796), oracle-side restatement for golden vectors
 # ---------------------------------------------------------------------------------------------
@@ -380,7 +481,7 @@ def pore_time_loop(pp, prob, bnd, n_steps, newton_kwargs=None, verbose=False, ca
     return out
 
 
-def edl_time_loop(ep, prob, n_steps, newton_kwargs=None, verbose=False):
+def edl_time_loop(ep, prob, n_steps, newton_kwargs=None, verbose=False, stabilization=False):
     """Dry-run loop of the 1D EDL driver (1D:633-796) without stabilisation: Newton (omega = 1), optional
     proton-flux controller (1D:766-793), u_n.assign(u)."""
     import copy
@@ -393,7 +494,13 @@ def edl_time_loop(ep, prob, n_steps, newton_kwargs=None, verbose=False):
     out = {"states": [], "newton_its": [], "residuals": [], "current_H_frac": []}
     prob.model = copy.deepcopy(prob.model)
     iH, iOH = ep.species.index("H"), ep.species.index("OH")
+    h_vertex = None
     for n in range(n_steps):
+        if stabilization:  # PNP + SUPG (1D:650-722): rho from the PREVIOUS step's potential, OH takes grad(u_H) (Q7)
+            assert not prob.model.steric, "the reference stabilises the PNP model only"
+            prob.supg_rho, h_vertex = supg_rho(prob.coords, prob.cells, prob.model.z, un.reshape(nv, nf)[:, nf - 1], h_vertex)
+            w = np.arange(nf - 1); w[iOH] = iH
+            prob.supg_w = w
         u, st = newton_solve(prob, u, un, **kw)
         f = u.reshape(nv, nf)[0, iH]
         if ep.H_OHP is not None:

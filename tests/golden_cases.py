@@ -17,6 +17,9 @@ EXTRA_EDL = {
     "edl5_na": (dict(L_n=5e-6, cation="Na", voltage_multiplier=-2.5), 3),
     "edl50_default": (dict(), 3),
     "edl10_hohp": (dict(L_n=10e-6, voltage_multiplier=-2.5, H_OHP=0.5, H2_FE=0.4), 4),
+    # PNP + SUPG stabilisation (reference 1D:597-722, --model PNP --stabilization Y)
+    "edl1_pnp_supg": (dict(L_n=1e-6, model="PNP", stabilization="Y", voltage_multiplier=-2.5), 4),
+    "edl10_pnp_supg_cs": (dict(L_n=10e-6, model="PNP", stabilization="Y", voltage_multiplier=-2.5, cation="Cs"), 4),
 }
 
 # 1D reaction-diffusion driver (reference 1D/rxn_diff_planar.py) on the same backend

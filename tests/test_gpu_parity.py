@@ -348,6 +348,41 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
 
 
+def test_supg_assembly_matches_oracle(edl1, gpu_lib):
+    """PNP + SUPG (reference 1D:687-714) with random nodal rho: residual and Jacobian against the oracle; switching the
+    terms off restores the plain PNP assembly; 3D handles refuse them."""
+    from gmpnp_amd.params import edl_parameters
+    from gmpnp_amd.problem import edl_problem
+    _, mesh, _ = edl1
+    ep = edl_parameters(L_n=1e-6, model="PNP", voltage_multiplier=-2.5)
+    prob = edl_problem(ep, mesh)
+    nv = mesh.num_vertices
+    u, un = random_state(nv, 6, seed=21)
+    rng = np.random.default_rng(22)
+    rho = rng.uniform(1e-9, 1e-4, (nv, 6)) * (np.asarray(prob.model.z) != 0)[None, :]
+    w = np.arange(6, dtype=np.int32)
+    w[1] = 0  # OH takes grad(u_H), SURVEY Q7
+    F0, A0 = O.assemble(prob, u, un)
+    p2 = copy.copy(prob)
+    p2.supg_rho, p2.supg_w = rho, w
+    Fs, As = O.assemble(p2, u, un)
+    assert relerr(Fs, F0) > 1e-6  # the terms are there
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.set_supg(rho, w)
+        F, _ = dev.assemble(True)
+        assert relerr(F, Fs) < 1e-12
+        J = dev.jacobian_csr()
+        assert abs(J - As).max() / abs(As).max() < 1e-12
+        x = rng.standard_normal(prob.ndof)
+        assert relerr(dev.spmv(x), As @ x) < 1e-12
+        dev.set_supg(None)
+        F, _ = dev.assemble(True)
+        assert relerr(F, F0) < 1e-12 and abs(dev.jacobian_csr() - A0).max() / abs(A0).max() < 1e-12
+        with pytest.raises(gpu_lib.GmpnpError):
+            dev.set_supg(-rho, w)
+
+
 @pytest.mark.parametrize("case", sorted(EXTRA_RXN1D))
 def test_rxn_diff_1d_matches_golden(case, tmp_path, monkeypatch, gpu_lib):
     """Reference 1D/rxn_diff_planar.py on the same kernels (valences 0, steric off, potential pinned by its Dirichlet

@@ -168,7 +168,7 @@ def test_project_gradient_of_linear_field(pore10):
     assert np.allclose(gproj, np.array([-2.0, 0.0, 3.0])[None, :], atol=1e-9)
 
 
-@pytest.mark.parametrize("case", ["edl1_pnp", "edl1_li", "edl5_na", "edl10_hohp"])
+@pytest.mark.parametrize("case", ["edl1_pnp", "edl1_li", "edl5_na", "edl10_hohp", "edl1_pnp_supg"])
 def test_oracle_reproduces_extra_edl_goldens(case):
     """The committed flag-surface goldens are what the oracle gives today (guards against silent oracle edits)."""
     import os
@@ -180,7 +180,69 @@ def test_oracle_reproduces_extra_edl_goldens(case):
     kw, nsteps = EXTRA_EDL[case]
     ep = edl_parameters(**kw)
     mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
-    out = O.edl_time_loop(ep, edl_problem(ep, mesh), nsteps)
+    out = O.edl_time_loop(ep, edl_problem(ep, mesh), nsteps, stabilization=(kw.get("stabilization") == "Y"))
     g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
     assert out["newton_its"] == list(g["newton_its"])
     assert np.allclose(out["states"], g["states"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("dim", [1, 3])
+def test_supg_terms_jacobian_is_the_derivative(dim):
+    """SUPG additions of the PNP stabilisation (reference 1D:687-714): exact Jacobian = central differences of the residual
+    addition; in 1D the closed-form residual = 6-point Gauss quadrature of the published integrand (with its grad(u_H) in
+    the OH term)."""
+    from gmpnp_amd.params import edl_parameters, pore_parameters
+    rng = np.random.default_rng(3)
+    if dim == 1:
+        m = edl_parameters(L_n=1e-6, model="PNP", voltage_multiplier=-2.5).model
+    else:
+        m = copy.deepcopy(pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9).model)
+        m.steric = False
+    ns, nc, nn = m.n_species, 4, dim + 1
+    X = rng.uniform(0, 0.05, (nc, nn, dim)) if dim == 3 else np.sort(rng.uniform(0, 1e-2, (nc, nn, 1)), axis=1)
+    U = np.concatenate([rng.uniform(.5, 1.5, (nc, nn, ns)), rng.uniform(-1, 0, (nc, nn, 1))], 2)
+    Un = np.concatenate([rng.uniform(.5, 1.5, (nc, nn, ns)), rng.uniform(-1, 0, (nc, nn, 1))], 2)
+    rho = rng.uniform(1e-6, 1e-4, (nc, nn, ns)) * (np.asarray(m.z) != 0)[None, None, :]
+    w = np.arange(ns)
+    w[1] = 0
+    F0, J = O.supg_terms(m, X, U, Un, rho, w)
+    eps, Jfd = 1e-6, np.zeros_like(J)
+    for b in range(nn):
+        for j in range(ns + 1):
+            Up, Um = U.copy(), U.copy()
+            Up[:, b, j] += eps
+            Um[:, b, j] -= eps
+            Jfd[:, :, :, b, j] = (O.supg_terms(m, X, Up, Un, rho, w, False)[0] - O.supg_terms(m, X, Um, Un, rho, w, False)[0]) / (2 * eps)
+    assert np.abs(J - Jfd).max() / np.abs(J).max() < 1e-8
+    assert not J[:, :, ns].any() and not F0[:, :, ns].any()  # the Poisson row is not stabilised
+    if dim == 1:
+        xs, ws = np.polynomial.legendre.leggauss(6)
+        lam, ws = np.stack([(1 - xs) / 2, (1 + xs) / 2], 1), ws / 2
+        vol, g = O._geometry(X)
+        z = np.asarray(m.z)
+        gradp = np.einsum("ea,ea->e", U[:, :, ns], g[:, :, 0])
+        gradw = np.einsum("eai,ea->ei", U[:, :, :ns][:, :, w], g[:, :, 0])
+        Fq = np.zeros_like(F0)
+        for q in range(len(ws)):
+            uq, unq, rq = (np.einsum("b,ebi->ei", lam[q], A) for A in (U[:, :, :ns], Un[:, :, :ns], rho))
+            R = -(m.rc0[None] + uq @ m.rc1.T + sum(m.rc2[None, :, t] * (uq[:, bj] * uq[:, bk])[:, None] for t, (bj, bk) in enumerate(m.bil)))
+            br = m.inv_dt * (uq - unq) + z[None] * gradw * gradp[:, None] + R
+            for a in range(2):
+                Fq[:, a, :ns] += -(ws[q] * vol)[:, None] * rq * z[None] * br * (gradp * g[:, a, 0])[:, None]
+        assert np.abs(F0 - Fq).max() / np.abs(F0).max() < 1e-13
+
+
+def test_supg_parameters_product_side_equals_oracle(edl1):
+    """gmpnp_amd.solver.supg_parameters (host glue of the driver) against the oracle's restatement of 1D:597-670, including
+    nodes on both branches of the Peclet switch."""
+    from gmpnp_amd.solver import project_cellwise, supg_parameters
+    ep, mesh, prob = edl1
+    nv = mesh.num_vertices
+    p = -5.0 * np.exp(-mesh.coords[:, 0] * 1.0e4) - 40.0 * mesh.coords[:, 0] ** 2  # steep near x = 0 (Pe > 1), gentle outside
+    r_prod, h_prod = supg_parameters(mesh.coords, mesh.cells, prob.model.z, p)
+    r_orac, h_orac = O.supg_rho(mesh.coords, mesh.cells, prob.model.z, p)
+    assert np.allclose(r_prod, r_orac, rtol=1e-13, atol=0) and np.allclose(h_prod, h_orac, rtol=1e-13, atol=0)
+    small = (h_orac ** 2 / 4)[:, None] * (np.asarray(prob.model.z) != 0)[None, :]
+    on_large = (r_orac != small).any(axis=1)
+    assert on_large.any() and (~on_large).any() and not r_orac[:, 4].any()  # both branches; CO2 (z = 0) untouched
+    assert np.allclose(project_cellwise(mesh.coords, mesh.cells, np.full(len(mesh.cells), 3.0)), 3.0)

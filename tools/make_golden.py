@@ -90,7 +90,8 @@ for key, (kw, steps) in EXTRA_EDL.items():
     ep = edl_parameters(**kw)
     mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), ep.mesh_name))
     prob = edl_problem(ep, mesh)
-    out = O.edl_time_loop(ep, prob, steps, verbose=True)
+    out = O.edl_time_loop(ep, prob, steps, verbose=True,
+                          stabilization=(kw.get("stabilization") == "Y" and kw.get("model") == "PNP"))
     np.savez_compressed(os.path.join(G, key + "_steps.npz"), states=out["states"], newton_its=np.array(out["newton_its"]),
                         residuals=pad_res(out["residuals"]))
     print(key, "done in %.1fs" % (time.time() - t), out["newton_its"])
