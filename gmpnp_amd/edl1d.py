@@ -4,9 +4,9 @@ reference 1D/MPNP_CO2ER_EDL.py (``solve_EDL`` 1D:66-989, CLI 1D:992-1118; SURVEY
 Kept quirks: ``--dry_run`` is ``type=bool`` so any value given on the command line is truthy; in
 non-dry-run mode the form keeps the first time step while ``t`` advances by the second (Q2) — here: the model's
 ``inv_dt`` is never changed after the first stage; the run then ends with NameError for ``time_step`` as the
-reference does (Q3).  ``--stabilization Y`` (PNP SUPG, 1D:597-722) is not part of this backend:
-for MPNP the reference only prints a warning and solves the unstabilised form, which is what happens here; for PNP
-it raises NotImplementedError.  Paths: ``$GMPNP_UTILITIES`` / ``$GMPNP_OUT`` (Q10)."""
+reference does (Q3).  ``--stabilization Y`` (1D:597-722): for MPNP the reference only prints a warning and solves the
+unstabilised form, which is what happens here; for PNP the SUPG terms are added on the device (``gmpnp_set_supg``) with
+the nodal parameters recomputed every step from the previous potential (``solver.supg_parameters``).  Paths: ``$GMPNP_UTILITIES`` / ``$GMPNP_OUT`` (Q10)."""
 from __future__ import annotations
 
 import argparse
