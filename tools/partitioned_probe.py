@@ -2,7 +2,8 @@
 Rehearsal on a one-GPU box: the ranks share the card and talk through gloo (on a multi-GPU node: backend nccl = RCCL, one
 rank per GPU).
 
-  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/partitioned_probe.py [backend]
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/partitioned_probe.py [backend] [config3]
+  (config3 = BASELINE configs[3]: L=100 nm, R=50 nm, 1.0 M, meant for 4 ranks)
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +17,7 @@ from gmpnp_amd.params import pore_parameters, utilities_dir
 from gmpnp_amd.problem import pore_problem
 
 backend = sys.argv[1] if len(sys.argv) > 1 else "gloo"
+config3 = len(sys.argv) > 2 and sys.argv[2] == "config3"  # BASELINE configs[3]: L=100 nm, R=50 nm, 1.0 M on the L_10_R_5 geometry
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
 torch.cuda.set_device(local)
@@ -25,9 +27,21 @@ if world > 1:
         tdist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         tdist.init_process_group(backend)
-pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
-mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-prob, _ = pore_problem(pp, mesh)
+if config3:
+    # the reference's L_100_R_50.xml was never published (.MISSING_LARGE_BLOBS:3); its scaled geometry (aspect R/L = 0.5) is that
+    # of L_10_R_5.xml, which is used here with that mesh's wall tolerance
+    from gmpnp_amd.mesh import mark_pore_boundaries, pore_wall_tolerance
+    from gmpnp_amd.problem import Problem, pore_dirichlet
+    pp = pore_parameters(concentration_elec=1.0, L=100e-9, R=50e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), "L_10_R_5.xml"))
+    bnd = mark_pore_boundaries(mesh, pp.aspect_pore, pore_wall_tolerance(10e-9, 5e-9))
+    dofs, vals = pore_dirichlet(pp, bnd)
+    prob = Problem(coords=mesh.coords, cells=mesh.cells, model=pp.model, wall_facets=bnd.ds_facets[2], exit_facets=bnd.ds_facets[3],
+                   bc_dofs=dofs, bc_vals=vals)
+else:
+    pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    prob, _ = pore_problem(pp, mesh)
 nv = mesh.num_vertices
 owner = dist.slab_owner(prob.coords, prob.cells, world)
 dom = dist.build_local_domain(prob, owner, rank, world)
