@@ -81,7 +81,10 @@ struct gmpnp_solver {
   // pinned read-back areas
   KrylovScalars* h_scal = nullptr; double* h_part = nullptr; int32_t* h_status = nullptr;
   // Krylov graph (one per preconditioner mode)
-  int graph_iters = 4;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped)
+  int graph_iters = 2;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped);
+                        // measured on the bench: 1 -> 453, 2 -> 463, 4 -> 456, 8 -> 436 Newton its/s
+  int krylov_hint = 0;  // expected iterations of the next solve (the same Newton iteration of the previous time step), 0 = none
+  int hint_by_newton_it[32] = {0};
   int last_krylov_iters[2] = {0, 0};
   bool jacobian_valid = false, precond_valid = false;
   int precond_mode = -1;
@@ -350,7 +353,11 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
   // next burst, then wait for the event), so the read-back latency hides behind queued work.  Kernels of a
   // converged solve exit at their first instruction.
-  int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, (3 * s->last_krylov_iters[use_coarse]) / 4);
+  // first burst: 7/8 of the count the same Newton iteration needed one time step ago (solves of one index resemble each
+  // other far more than consecutive solves do: the first of a step is cold, the others are warm-started), else 3/4 of
+  // the previous solve
+  const int expect = s->krylov_hint > 0 ? (7 * s->krylov_hint) / 8 : (3 * s->last_krylov_iters[use_coarse]) / 4;
+  int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, expect);
   if (restart) first = B;  // a restart pass only has to remove the drift
   first = ((first + B - 1) / B) * B;
   int next_k = 0;  // iteration index of the next launch (the device stops advancing once `done` is set)
@@ -647,6 +654,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // whatever is left
       // x0 = (1-w) dx_k + (1-w)^2 (dx_k - (1-w) dx_{k-1}): first-order prediction plus the second-order term observed
       // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (GMPNP_WARM_START=1: first order only)
+      s->krylov_hint = st.iterations < 32 ? s->hint_by_newton_it[st.iterations] : 0;
       const double q = 1.0 - o.relaxation_parameter;
       double wa = 0.0, wb = 0.0;
       if (s->warm_start && st.iterations > 0 && q != 0.0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
@@ -657,6 +665,8 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
                                o.krylov_maximum_iterations, &ls, 500, wa, wb);
       // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
+      if (st.iterations < 32) s->hint_by_newton_it[st.iterations] = ls.iterations;
+      s->krylov_hint = 0;
       if (coarse_fresh) { s->krylov_fresh_iters = ls.iterations; s->coarse_refresh_due = false; }
       else if (ls.iterations > 2 * s->krylov_fresh_iters + 10) s->coarse_refresh_due = true;
       if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
