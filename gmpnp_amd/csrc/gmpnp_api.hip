@@ -345,9 +345,10 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
   init.rr0 = bnorm * bnorm;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
-  s->h_scal[0] = init;
-  HIP_TRY(hipMemcpyAsync(s->scal.p, s->h_scal, sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));  // h_scal is reused for read-back below
+  // the initial values travel from their own pinned slot (slots 0/1 are the read-back buffers): no host wait here; the
+  // slot is rewritten by the next solve only, which starts after this one's final read-back
+  s->h_scal[2] = init;
+  HIP_TRY(hipMemcpyAsync(s->scal.p, &s->h_scal[2], sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
   const int B = s->graph_iters;
   // Bursts of B iterations.  The first burst is 3/4 of what the previous solve with this preconditioner
   // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
@@ -845,7 +846,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
   HIP_TRY(s->part_f.alloc((size_t)3 * s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
-  HIP_TRY(hipHostMalloc((void**)&s->h_scal, 2 * sizeof(KrylovScalars)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_scal, 3 * sizeof(KrylovScalars)));
   for (auto& e : s->ev_poll) HIP_TRY(hipEventCreate(&e));
   if (const char* gi = std::getenv("GMPNP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::atoi(gi));
   if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));
