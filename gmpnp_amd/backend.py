@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgmpnp.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_CONVERGED, ERR_LINEAR, ERR_NUMERIC = 0, -1, -2, -3, -4, -5
-LINEAR_TWOLEVEL, LINEAR_JACOBI, LINEAR_BLOCK_TRIDIAGONAL = 0, 1, 2
+LINEAR_TWOLEVEL, LINEAR_JACOBI, LINEAR_BLOCK_TRIDIAGONAL, LINEAR_BAND_LU = 0, 1, 2, 3
 MAX_HISTORY = 64
 
 EXPORTS = [
@@ -51,7 +51,8 @@ class CNewtonStats(ctypes.Structure):
     _fields_ = [("iterations", c_int32), ("converged", c_int32), ("krylov_iterations", c_int32),
                 ("n_residuals", c_int32), ("residuals", c_double * MAX_HISTORY),
                 ("krylov_per_iteration", c_int32 * MAX_HISTORY),
-                ("ms_assemble", c_double), ("ms_setup", c_double), ("ms_krylov", c_double), ("ms_total", c_double)]
+                ("ms_assemble", c_double), ("ms_setup", c_double), ("ms_krylov", c_double), ("ms_total", c_double),
+                ("direct_solves", c_int32), ("pad_", c_int32)]
 
 
 class CLinearStats(ctypes.Structure):
@@ -164,8 +165,10 @@ def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -
 def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptions:
     """Translate the reference's ``solver_parameters`` dict (3D:789-798, 1D:357-364) + [3P] DOLFIN
     defaults.  Direct solvers ('default', 'lu', 'mumps', 'umfpack', 'superlu', 'petsc') map to the
-    "exact-equivalent" two-level BiCGStab at 1e-10 relative residual; 'bicgstab' honours
-    ``preconditioner`` ('jacobi' | anything else -> two-level) and a ``krylov_solver`` sub-dict."""
+    "exact-equivalent" two-level BiCGStab at 1e-10 relative residual (a 3D solve that does not converge falls back
+    to the block-banded LU inside the library; ``GMPNP_3D_DIRECT=1`` maps them to that LU from the start, the literal
+    reading of 'mumps'); 'band_lu' asks for the LU by name; 'bicgstab' honours ``preconditioner``
+    ('jacobi' | anything else -> two-level) and a ``krylov_solver`` sub-dict."""
     sp = dict(solver_parameters or {})
     if sp.get("nonlinear_solver", "newton") != "newton":
         raise RuntimeError("nonlinear_solver %r is not available" % sp.get("nonlinear_solver"))
@@ -179,7 +182,11 @@ def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptio
     ks = dict(ns.get("krylov_solver", {}))
     if lin in ("default", "lu", "mumps", "umfpack", "superlu", "superlu_dist", "petsc"):
         # exact-equivalent modes: 1D -> block-tridiagonal direct solve, 3D -> two-level BiCGStab at 1e-10
-        o.linear_solver = LINEAR_BLOCK_TRIDIAGONAL if dim == 1 else LINEAR_TWOLEVEL
+        direct3d = os.environ.get("GMPNP_3D_DIRECT", "0") not in ("", "0")
+        o.linear_solver = LINEAR_BLOCK_TRIDIAGONAL if dim == 1 else (LINEAR_BAND_LU if direct3d else LINEAR_TWOLEVEL)
+        o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-10))
+    elif lin in ("band_lu", "gmpnp_band_lu"):
+        o.linear_solver = LINEAR_BLOCK_TRIDIAGONAL if dim == 1 else LINEAR_BAND_LU
         o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-10))
     elif lin == "bicgstab":
         o.linear_solver = LINEAR_JACOBI if ns.get("preconditioner", "default") == "jacobi" else LINEAR_TWOLEVEL
@@ -372,7 +379,7 @@ class DeviceSolver:
                  "residuals": [st.residuals[i] for i in range(st.n_residuals)],
                  "krylov_per_iteration": [st.krylov_per_iteration[i] for i in range(min(st.iterations, MAX_HISTORY))],
                  "ms_assemble": st.ms_assemble, "ms_setup": st.ms_setup, "ms_krylov": st.ms_krylov,
-                 "ms_total": st.ms_total}
+                 "ms_total": st.ms_total, "direct_solves": st.direct_solves}
         if code == ERR_NOT_CONVERGED and not error_on_nonconvergence:
             return stats
         self._check(code)

@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include "gmpnp_kernels.h"
+#include "gmpnp_band_lu.h"
 
 using namespace gmpnp;
 
@@ -108,6 +109,12 @@ struct gmpnp_solver {
   int64_t spmv_launched = 0, spmv_sampled = 0; double spmv_us_sum = 0.0;
   // block-tridiagonal direct solver (1D): cyclic-reduction pyramid
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
+  // block-banded LU (3D): direct solver / fallback of the Krylov solve; storage is allocated on first use
+  DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
+  int direct_fallback = 1;      // GMPNP_DIRECT_FALLBACK=0: a failed Krylov solve is an error again
+  double lu_max_gb = 48.0;      // GMPNP_BAND_LU_MAX_GB: largest band storage the fallback may allocate
+  int direct_solves = 0;        // band LU solves since create (factorisations)
+  int direct_sticky = 0;        // Newton solves that still go straight to the band LU after a Krylov failure
   hipEvent_t ev_phase[6] = {};
   hipEvent_t ev_poll[2] = {};
 
@@ -598,6 +605,81 @@ int tri_apply(gmpnp_solver* s, double* dst, double scale_dst, double scale_x) {
   return GMPNP_OK;
 }
 
+// ---- 3D direct solver: block-banded LU ------------------------------------------------------------
+template <int NF>
+int band_prepare(gmpnp_solver* s) {
+  if (s->lu_ready) return GMPNP_OK;
+  const Topology& t = s->t;
+  const int n = t.nv, b = t.lu_band;
+  const double gb = (double)n * (2.0 * b + 1.0) * NF * NF * sizeof(double) / 1e9;
+  char buf[200];
+  if (gb > s->lu_max_gb) {
+    snprintf(buf, sizeof buf, "block-banded LU needs %.1f GB (%d node blocks, band %d), above GMPNP_BAND_LU_MAX_GB = %.1f", gb, n, b, s->lu_max_gb);
+    return fail(GMPNP_ERR_INVALID, buf);
+  }
+  const size_t ring = (size_t)(b + 1) * NF * sizeof(double);
+  if (ring > 150u * 1024u) return fail(GMPNP_ERR_INVALID, "block-banded LU: the band does not fit the LDS ring of the substitution kernel");
+  HIP_TRY(s->lu_band.alloc((size_t)n * (2 * b + 1) * NF * NF, false));
+  HIP_TRY(s->lu_dinv.alloc((size_t)n * NF * NF)); HIP_TRY(s->lu_y.alloc((size_t)n * NF));
+  HIP_TRY(s->lu_pos.upload(t.lu_pos)); HIP_TRY(s->lu_node.upload(t.lu_node));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_band_solve<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring));
+  s->lu = BandLU{s->lu_band.p, s->lu_dinv.p, s->lu_pos.p, s->lu_node.p, n, b};
+  s->lu_ready = true;
+  return GMPNP_OK;
+}
+
+// factorise the assembled Jacobian (c.vals)
+template <int NF>
+int band_factor(gmpnp_solver* s) {
+  int rc = band_prepare<NF>(s); if (rc) return rc;
+  const BandLU& lu = s->lu;
+  constexpr int G = kBandThreads / (NF * NF);
+  HIP_TRY(hipMemsetAsync(lu.band, 0, s->lu_band.n * sizeof(double), s->stream));
+  hipLaunchKernelGGL((k_band_scatter<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c, lu);
+  hipLaunchKernelGGL((k_band_step<NF>), dim3(1, 1), dim3(kBandThreads), 0, s->stream, lu, -1, s->status.p);
+  for (int k = 0; k + 1 < lu.n; ++k) {
+    const int w = std::min(lu.b, lu.n - 1 - k);
+    hipLaunchKernelGGL((k_band_step<NF>), dim3(grid_for(w, kBandColChunk), grid_for(w, G)), dim3(kBandThreads), 0, s->stream, lu, k, s->status.p);
+  }
+  HIP_TRY(hipGetLastError());
+  s->direct_solves++;
+  return GMPNP_OK;
+}
+
+template <int NF>
+int band_substitute(gmpnp_solver* s, const double* rhs, double* x) {
+  hipLaunchKernelGGL((k_band_solve<NF>), dim3(1), dim3(NF * kWave), (size_t)(s->lu.b + 1) * NF * sizeof(double), s->stream, s->lu, rhs, x, s->lu_y.p);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+// Direct solve of J dx = b with b in kb: dx in kx, checked and refined with the true residual (the pivoting is
+// restricted to the node blocks).  stats->residual_norm = ||b - J dx||.
+template <int NF>
+int band_solve(gmpnp_solver* s, double bnorm, double rtol, double atol, gmpnp_linear_stats_t* st) {
+  const double tol = std::max(rtol * bnorm, atol);
+  int rc = band_factor<NF>(s); if (rc) return rc;
+  rc = band_substitute<NF>(s, s->kb.p, s->kx.p); if (rc) return rc;
+  double rn = 0.0, best = 0.0;
+  rc = true_residual<NF>(s, &rn); if (rc) return rc;   // kr = b - J kx
+  HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (*s->h_status & 2) return fail(GMPNP_ERR_LINEAR, "block-banded LU: singular pivot block");
+  for (int round = 0; round < 3 && rn == rn && rn > tol; ++round) {   // iterative refinement
+    best = rn;
+    rc = band_substitute<NF>(s, s->kr.p, s->ks.p); if (rc) return rc;
+    hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->kx.p, (const double*)s->ks.p, 1.0, (int)s->ndof);
+    rc = true_residual<NF>(s, &rn); if (rc) return rc;
+    if (!(rn < 0.5 * best)) break;   // attainable accuracy reached
+  }
+  if (st) { st->converged = (rn == rn && rn <= 1e3 * tol) ? 1 : 0; st->residual_norm = rn; st->rhs_norm = bnorm; }
+  if (!(rn == rn) || rn > 1e3 * tol) {
+    char buf[200];
+    snprintf(buf, sizeof buf, "block-banded LU: ||b - J x|| = %.3e after refinement, ||b|| = %.3e", rn, bnorm);
+    return fail(GMPNP_ERR_LINEAR, buf);
+  }
+  return GMPNP_OK;
+}
+
 std::string status_message(int flags) {
   std::string m;
   if (flags & 1) m += "1 - sum_j a_j u_j <= 0 at a quadrature point; ";
@@ -641,6 +723,18 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       } else {
         return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh");
       }
+    } else if (o.linear_solver == GMPNP_LINEAR_BAND_LU || s->direct_sticky > 0) {
+      if constexpr (DIM == 3) {
+        HIP_TRY(hipMemcpyAsync(s->kb.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+        gmpnp_linear_stats_t ls{};
+        rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ls); if (rc) return rc;
+        st.direct_solves++;
+        hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
+                           -o.relaxation_parameter, (int)s->ndof);
+      } else {
+        return fail(GMPNP_ERR_INVALID, "block-banded LU is the 3D direct solver (1D meshes: GMPNP_LINEAR_BLOCK_TRIDIAGONAL)");
+      }
     } else {
       // The coarse inverse is reused for up to coarse_lag Newton iterations, unless the state was just set from outside
       // (first solve of a run: the Jacobian changes a lot between iterations) or the last reuse cost iterations.
@@ -672,6 +766,19 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       else if (ls.iterations > 2 * s->krylov_fresh_iters + 10) s->coarse_refresh_due = true;
       if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
       st.krylov_iterations += ls.iterations;
+      if constexpr (DIM == 3) {
+        // The reference's linear solver is direct (MUMPS, 3D:792): a Krylov solve that does not converge is not an
+        // error there.  The block-banded LU takes over for this system, the rest of this Newton solve and the
+        // next few solves (kb still holds b).
+        if (rc == GMPNP_ERR_LINEAR && s->direct_fallback) {
+          const std::string why = g_err;
+          HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+          gmpnp_linear_stats_t ds{};
+          rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ds);
+          if (rc) g_err = why + "; direct fallback: " + g_err;
+          else { st.direct_solves++; s->direct_sticky = 8; s->coarse_refresh_due = true; }
+        }
+      }
       if (rc) {
         HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
         if (*s->h_status) g_err += " [" + status_message(*s->h_status) + "]";
@@ -702,6 +809,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     done = conv(r);
   }
   s->state_jumped = false;
+  if (s->direct_sticky > 0 && o.linear_solver != GMPNP_LINEAR_BAND_LU) s->direct_sticky--;
   if (st.iterations > 0 && DIM == 3 && s->warm_start > 2) {  // total update of this solve, in the sign convention of dx (u_new = u - omega dx)
     hipLaunchKernelGGL(k_diff, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->kstep.p, (const double*)s->kstart.p,
                        (const double*)s->u.p, (int)s->ndof);
@@ -852,6 +960,8 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_COARSE_LAG")) s->coarse_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_WARM_START")) s->warm_start = std::atoi(pl);
+  if (const char* pl = std::getenv("GMPNP_DIRECT_FALLBACK")) s->direct_fallback = std::atoi(pl);
+  if (const char* pl = std::getenv("GMPNP_BAND_LU_MAX_GB")) s->lu_max_gb = std::atof(pl);
   {  // fused launch form only where every workgroup of a launch is resident at once (3 x 512 threads per CU): there the
      // hand-over inside the launch beats a launch boundary (+5 % on L_50_R_5); with more tiles than slots it loses (-4 %)
     hipDeviceProp_t prop{};
@@ -979,7 +1089,7 @@ int gmpnp_assign_previous(gmpnp_solver* s) {
 int gmpnp_newton_solve(gmpnp_solver* s, const gmpnp_newton_options_t* o, gmpnp_newton_stats_t* stats) {
   if (!s || !o) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (o->maximum_iterations < 0 || o->krylov_maximum_iterations < 1) return fail(GMPNP_ERR_INVALID, "bad iteration limits");
-  if (o->linear_solver < 0 || o->linear_solver > GMPNP_LINEAR_BLOCK_TRIDIAGONAL) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
+  if (o->linear_solver < 0 || o->linear_solver > GMPNP_LINEAR_BAND_LU) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
   if (o->linear_solver == GMPNP_LINEAR_BLOCK_TRIDIAGONAL && !s->tri_ok)
     return fail(GMPNP_ERR_INVALID, "block-tridiagonal solver needs a 1D mesh in path order");
   gmpnp_newton_stats_t local{};
@@ -1059,7 +1169,7 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
                        int32_t maxit, gmpnp_linear_stats_t* stats) {
   if (!s || !b || !x) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
-  if (mode < 0 || mode > GMPNP_LINEAR_BLOCK_TRIDIAGONAL) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
+  if (mode < 0 || mode > GMPNP_LINEAR_BAND_LU) return fail(GMPNP_ERR_INVALID, "unknown linear_solver");
   if (maxit < 1) return fail(GMPNP_ERR_INVALID, "max_iterations < 1");
   HIP_TRY(hipSetDevice(s->opts.device_id));
   HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
@@ -1075,6 +1185,16 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
     HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (*s->h_status & 14) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
     if (stats) { stats->iterations = 1; stats->converged = 1; stats->residual_norm = 0.0; stats->rhs_norm = bn; }
+    return download_vec(s, s->kx.p, x);
+  }
+  if (mode == GMPNP_LINEAR_BAND_LU) {
+    if (s->dim != 3) return fail(GMPNP_ERR_INVALID, "block-banded LU is the 3D direct solver (1D meshes: GMPNP_LINEAR_BLOCK_TRIDIAGONAL)");
+    HIP_TRY(hipMemcpyAsync(s->kb.p, s->kr.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    gmpnp_linear_stats_t ls{};
+    rc = band_solve<9>(s, bn, rtol, atol, &ls);
+    ls.iterations = 1;
+    if (stats) *stats = ls;
+    if (rc) return rc;
     return download_vec(s, s->kx.p, x);
   }
   GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));

@@ -176,6 +176,18 @@ struct Topology {
   std::vector<TileRec> tile_rec;
   int col_stride = 0;
   int ntiles = 0, tile_slots = 0;
+  std::vector<int32_t> lu_node, lu_pos;   // elimination order of the block-banded LU: lu_node[position] = internal node
+  int lu_band = 0;                        // max |lu_pos[I] - lu_pos[J]| over the blocks of the pattern
+};
+
+// Block-banded LU of the Jacobian in the elimination order above (direct fallback of the 3D Krylov solve).
+// Block (p, q), |p - q| <= b, lives at band[(p * (2b+1) + (q - p + b)) * NF*NF], row major.
+struct BandLU {
+  double* band;           // [n][2b+1][NF][NF]
+  double* dinv;           // [n][NF][NF] inverses of the pivot blocks
+  const int32_t* lu_pos;  // [nv] internal node -> position
+  const int32_t* lu_node; // [nv] position -> internal node
+  int32_t n, b;
 };
 
 // Builds every table above; returns an error message or "" on success.

@@ -2,6 +2,7 @@
 // per-block element contribution lists (race-free gather assembly), SELL slices, slab aggregates.
 // Plays the role of DOLFIN's dofmap / sparsity-pattern builder ([3P]).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -25,7 +26,16 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
       const int ia = first.iperm[a], ib = first.iperm[b];
       return (first.rowptr[ia + 1] - first.rowptr[ia]) > (first.rowptr[ib + 1] - first.rowptr[ib]);
     });
-  return build_pass(m, perm2.data(), nf, first.nagg, true, t);
+  err = build_pass(m, perm2.data(), nf, first.nagg, true, t);
+  if (!err.empty()) return err;
+  // Elimination order of the block-banded direct solver: the caller's slab order (sorted along the pore axis), NOT the
+  // degree-sorted internal order, whose bandwidth is a whole aggregate.
+  t.lu_node.resize(t.nv); t.lu_pos.resize(t.nv);
+  for (int p = 0; p < t.nv; ++p) { const int I = t.iperm[first.perm[p]]; t.lu_node[p] = I; t.lu_pos[I] = p; }
+  t.lu_band = 0;
+  for (int I = 0; I < t.nv; ++I)
+    for (int k = t.rowptr[I]; k < t.rowptr[I + 1]; ++k) t.lu_band = std::max(t.lu_band, std::abs(t.lu_pos[I] - t.lu_pos[t.cols[k]]));
+  return "";
 }
 
 static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t) {

@@ -100,7 +100,9 @@ typedef struct {
 typedef enum {
   GMPNP_LINEAR_BICGSTAB_TWOLEVEL = 0, /* BiCGStab, right-preconditioned by node-block Jacobi + slab-aggregate coarse correction */
   GMPNP_LINEAR_BICGSTAB_JACOBI = 1,   /* BiCGStab, node-block Jacobi only ([3P] 'bicgstab' + 'jacobi') */
-  GMPNP_LINEAR_BLOCK_TRIDIAGONAL = 2  /* direct block-tridiagonal LU (1D meshes only) */
+  GMPNP_LINEAR_BLOCK_TRIDIAGONAL = 2, /* direct block-tridiagonal LU (1D meshes only) */
+  GMPNP_LINEAR_BAND_LU = 3            /* direct block-banded LU in slab order (3D meshes); also what a 3D Krylov solve
+                                         that does not converge falls back to, MUMPS never failing in the reference */
 } gmpnp_linear_kind;
 
 /* newton_solver parameter dict of the reference (3D:789-798, 1D:357-364) + krylov_solver sub-dict. */
@@ -123,6 +125,8 @@ typedef struct {
   double residuals[GMPNP_MAX_NEWTON_HISTORY]; /* ||b||_2 before iteration 0 and after each update */
   int32_t krylov_per_iteration[GMPNP_MAX_NEWTON_HISTORY];
   double ms_assemble, ms_setup, ms_krylov, ms_total; /* host wall clock, ms */
+  int32_t direct_solves;        /* Newton iterations whose system the block-banded LU solved (mode 3 or fallback) */
+  int32_t pad_;
 } gmpnp_newton_stats_t;
 
 typedef struct {

@@ -9,6 +9,9 @@ EXTRA_PORE = {
     "pore10_pub_v25": (dict(concentration_elec=0.5, L=10e-9, R=5e-9, voltage_multiplier=-2.5, as_published=True), 3),
     "pore10_1M": (dict(concentration_elec=1.0, L=10e-9, R=5e-9), 2),
     "pore25_fe": (dict(concentration_elec=0.5, L=25e-9, R=5e-9, H2_FE=0.2, current_rough=1000.0), 2),
+    # thinnest pore of the sweep (BASELINE configs[4]): from time step 3 on BiCGStab no longer converges and the
+    # block-banded LU takes over, as MUMPS does in the reference
+    "pore50_r1": (dict(concentration_elec=0.5, L=50e-9, R=1e-9), 6),
 }
 
 EXTRA_EDL = {

@@ -183,6 +183,83 @@ def test_newton_nonconvergence_is_an_error(pore10, gpu_lib):
         s.close()
 
 
+BAND_09 = {"nonlinear_solver": "newton", "newton_solver": dict(MUMPS_09["newton_solver"], linear_solver="band_lu")}
+
+
+def test_band_lu_matches_sparse_lu(pore10, gpu_lib):
+    """The 3D direct solver (block-banded LU in slab order) against SciPy's sparse LU on the oracle's Jacobian."""
+    prob = pore10[2]
+    u, un = random_state(prob.coords.shape[0], prob.nf - 1, seed=5)
+    Fo, Ao = O.assemble(prob, u, un)
+    lu = spla.splu(Ao.tocsc())
+    rng = np.random.default_rng(8)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.assemble(True)
+        for rhs in (Fo, rng.standard_normal(prob.ndof)):
+            x, st = dev.linear_solve(rhs, gpu_lib.LINEAR_BAND_LU)
+            # refinement stops at the requested 1e-10 relative residual; on this random (unphysical) state
+            # ||x|| ~ 3e4 ||b||, so the solution error is looser than the residual
+            assert st["converged"] and relerr(Ao @ x, rhs) < 2e-10 and relerr(x, lu.solve(rhs)) < 1e-6
+            x2, _ = dev.linear_solve(rhs, gpu_lib.LINEAR_BAND_LU)
+            assert np.array_equal(x, x2)  # no atomics, fixed elimination order
+        xz, _ = dev.linear_solve(np.zeros(prob.ndof), gpu_lib.LINEAR_BAND_LU)
+        assert not xz.any()
+
+
+def test_band_lu_is_3d_only(edl1, gpu_lib):
+    prob = edl1[2]
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(np.zeros(prob.ndof), np.zeros(prob.ndof))
+        dev.assemble(True)
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.linear_solve(np.ones(prob.ndof), gpu_lib.LINEAR_BAND_LU)
+        assert ei.value.code == gpu_lib.ERR_INVALID
+    # ... and the name maps to the 1D direct solver there
+    assert gpu_lib.newton_options(BAND_09, dim=1).linear_solver == gpu_lib.LINEAR_BLOCK_TRIDIAGONAL
+
+
+def test_newton_with_band_lu_matches_golden(gpu_lib):
+    """'mumps' read literally: every Newton system solved by the direct solver; same iterates as the golden steps."""
+    from gmpnp_amd.pore3d import PoreRun
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    run = PoreRun(num_steps=2, concentration_elec=0.5, L=10e-9, R=5e-9, solver_parameters=BAND_09)
+    try:
+        for k in range(2):
+            st = run.step(verbose=False)
+            assert st["direct_solves"] == st["iterations"] == int(g["newton_its"][k]) and st["krylov_iterations"] == 0
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
+    finally:
+        run.sys.close()
+
+
+def test_krylov_failure_falls_back_to_band_lu(pore10, gpu_lib, monkeypatch):
+    """The reference's linear solver is direct and cannot fail to converge; a BiCGStab solve that does (here: an
+    iteration cap of 3) hands the system to the block-banded LU, and the Newton iterates stay those of the golden
+    steps.  GMPNP_DIRECT_FALLBACK=0 turns the failure back into the error it used to be."""
+    from gmpnp_amd.solver import GMPNPSystem
+    prob = pore10[2]
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    sp = copy.deepcopy(MUMPS_09)
+    sp["newton_solver"]["krylov_solver"] = {"maximum_iterations": 3}
+    s = GMPNPSystem(prob)
+    try:
+        s.initialise([1.0] * 8 + [0.0])
+        st = s.solve(sp)
+        assert st["iterations"] == int(g["newton_its"][0]) and st["direct_solves"] == st["iterations"]
+        assert relerr(s.dev.get_state(), g["states"][0]) < 1e-8
+    finally:
+        s.close()
+    monkeypatch.setenv("GMPNP_DIRECT_FALLBACK", "0")
+    s = GMPNPSystem(prob)
+    try:
+        s.initialise([1.0] * 8 + [0.0])
+        with pytest.raises(RuntimeError, match="BiCGStab stopped without convergence"):
+            s.solve(sp)
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("case,nsteps", [("pore10", 3), ("pore50", 2)])
 def test_pore_time_loop_matches_golden(case, nsteps, gpu_lib):
     """The driver's loop (Newton, median -> Sechenov -> new bc4, u_n.assign(u)) against the oracle's golden steps."""
