@@ -115,6 +115,7 @@ struct gmpnp_solver {
   double lu_max_gb = 48.0;      // GMPNP_BAND_LU_MAX_GB: largest band storage the fallback may allocate
   int direct_solves = 0;        // band LU solves since create (factorisations)
   int direct_sticky = 0;        // Newton solves that still go straight to the band LU after a Krylov failure
+  int direct_backoff = 0;       // length of the last such stretch (doubles with every new failure, resets on a converged Krylov solve)
   hipEvent_t ev_phase[6] = {};
   hipEvent_t ev_poll[2] = {};
 
@@ -762,6 +763,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
       if (st.iterations < 32) s->hint_by_newton_it[st.iterations] = ls.iterations;
       s->krylov_hint = 0;
+      if (rc == GMPNP_OK && st.iterations == 0) s->direct_backoff /= 2;  // BiCGStab works again
       if (coarse_fresh) { s->krylov_fresh_iters = ls.iterations; s->coarse_refresh_due = false; }
       else if (ls.iterations > 2 * s->krylov_fresh_iters + 10) s->coarse_refresh_due = true;
       if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
@@ -776,7 +778,11 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
           gmpnp_linear_stats_t ds{};
           rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ds);
           if (rc) g_err = why + "; direct fallback: " + g_err;
-          else { st.direct_solves++; s->direct_sticky = 8; s->coarse_refresh_due = true; }
+          else {  // back off: 8, 16, ... 256 Newton solves before BiCGStab is tried again (a failed try costs ~0.25 s)
+            st.direct_solves++; s->coarse_refresh_due = true;
+            s->direct_backoff = std::min(256, std::max(8, 2 * s->direct_backoff));
+            s->direct_sticky = s->direct_backoff;
+          }
         }
       }
       if (rc) {

@@ -88,27 +88,41 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
     const int w = min(lu.b, lu.n - 1 - k);
     const int q0 = k + 1 + blockIdx.x * QC, p = k + 1 + blockIdx.y * G + g;
     const int nq = min(QC, k + w + 1 - q0);
-    if (t < BB) sD[t] = lu.dinv[(size_t)k * BB + t];
-    __syncthreads();
+    // every global operand is requested before the first barrier (clamped indices, masks afterwards): one memory
+    // latency per launch instead of three dependent ones; the launches of a factorisation run back to back
+    constexpr int UP = (QC * BB + kBandThreads - 1) / kBandThreads;   // U' entries per thread
+    const bool act = g < G && p <= k + w;
+    const int pc = min(p, k + w);
+    const double dk = lu.dinv[(size_t)k * BB + min(t, BB - 1)];
     const double* Ak = band_at<NF>(lu, k, q0);
-    for (int idx = t; idx < nq * BB; idx += kBandThreads) {
-      const int qq = idx / BB, ee = idx - qq * BB, m = ee / NF, jj = ee - m * NF;
-      const double* a = Ak + (size_t)qq * BB + jj;
+    double a[UP][NF];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const int idx = min(t + u * kBandThreads, nq * BB - 1), qq = idx / BB, ee = idx - qq * BB, jj = ee % NF;
+#pragma unroll
+      for (int l = 0; l < NF; ++l) a[u][l] = Ak[(size_t)qq * BB + l * NF + jj];
+    }
+    const double* Lp = band_at<NF>(lu, pc, k) + i * NF;
+    double l[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) l[m] = Lp[m];
+    double* C = band_at<NF>(lu, pc, q0) + e;
+    double cv[QC];
+#pragma unroll
+    for (int qq = 0; qq < QC; ++qq) cv[qq] = C[(size_t)min(qq, nq - 1) * BB];
+    if (t < BB) sD[t] = dk;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const int idx = t + u * kBandThreads;
+      const int ic = min(idx, nq * BB - 1), qq = ic / BB, ee = ic - qq * BB, m = ee / NF;
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < NF; ++l) acc += sD[m * NF + l] * a[l * NF];
-      sU[idx] = acc;
+      for (int ll = 0; ll < NF; ++ll) acc += sD[m * NF + ll] * a[u][ll];
+      if (idx < nq * BB) sU[idx] = acc;
     }
     __syncthreads();
-    if (g < G && p <= k + w) {
-      const double* Lp = band_at<NF>(lu, p, k) + i * NF;
-      double l[NF];
-#pragma unroll
-      for (int m = 0; m < NF; ++m) l[m] = Lp[m];
-      double* C = band_at<NF>(lu, p, q0) + e;
-      double cv[QC];
-#pragma unroll
-      for (int qq = 0; qq < QC; ++qq) cv[qq] = C[(size_t)min(qq, nq - 1) * BB];
+    if (act) {
 #pragma unroll
       for (int qq = 0; qq < QC; ++qq) {
         double acc = cv[qq];
@@ -141,58 +155,108 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
   }
 }
 
+// One lane's share of a band row (entries (qo, j) of the qo-th block behind `row`, row stride already applied), in
+// batches of kBandDotBatch entries per lane: all loads of a batch go out on clamped indices before the first use, the
+// masks come afterwards (a plain loop waits for every load before it issues the next: one memory latency per 64
+// entries; 54 -> 27 ms per substitution on the pore meshes).  Requesting the first batch of the NEXT row one step
+// ahead was tried and lost: two batches of doubles in flight per lane spill at 9 waves per workgroup.
+constexpr int kBandDotBatch = 16;
+template <int NF>
+__device__ __forceinline__ void band_row_load(const double* __restrict__ row, int count, int base, int lane, double (&v)[kBandDotBatch]) {
+  constexpr int BB = NF * NF;
+  const int last = max(count - 1, 0);
+#pragma unroll
+  for (int u = 0; u < kBandDotBatch; ++u) {
+    const int idx = min(base + u * kWave + lane, last), qo = idx / NF, jj = idx - qo * NF;
+    v[u] = row[(size_t)qo * BB + jj];
+  }
+}
+template <int NF>
+__device__ __forceinline__ double band_row_mac(const double (&v)[kBandDotBatch], const double* ring, int count, int base, int rb, int R, int lane) {
+  const int last = max(count - 1, 0);
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < kBandDotBatch; ++u) {
+    const int raw = base + u * kWave + lane, idx = min(raw, last), qo = idx / NF, jj = idx - qo * NF;
+    int rr = rb + qo; rr -= (rr >= R) ? R : 0;
+    acc += (raw < count) ? v[u] * ring[rr * NF + jj] : 0.0;
+  }
+  return acc;
+}
+
 // x = U^-1 L^-1 rhs.  ONE workgroup of NF waves; wave i owns row i of the current block row and reduces its band
 // dot product, then NF threads apply D_k^-1.  The last b solution blocks live in an LDS ring ((b+1) * NF doubles,
 // dynamic shared memory).  rhs and x are in internal node order, y is a work vector in elimination order.
+// Every step is a chain band row -> dot -> D_k^-1 -> ring; whatever does not depend on the previous block (the band
+// row, D_k^-1, the right-hand side) is requested ahead of the chain.
 template <int NF>
 __global__ __launch_bounds__(NF * kWave) void k_band_solve(const BandLU lu, const double* __restrict__ rhs, double* __restrict__ x,
                                                             double* __restrict__ y) {
-  constexpr int BB = NF * NF;
+  constexpr int U = kBandDotBatch;
   extern __shared__ double ring[];   // [(b+1)][NF]
   __shared__ double st[NF];
   const int t = threadIdx.x, wv = t / kWave, lane = t - wv * kWave;
   const int n = lu.n, b = lu.b, R = b + 1;
+  for (int idx = t; idx < n * NF; idx += NF * kWave) {   // right-hand side in elimination order
+    const int k = idx / NF;
+    y[idx] = rhs[(size_t)lu.lu_node[k] * NF + (idx - k * NF)];
+  }
+  __syncthreads();
+  const int tc = t < NF ? t : 0;
   // forward: y_k = D_k^-1 (rhs_k - sum_{q<k} A_kq y_q)
   for (int k = 0; k < n; ++k) {
-    const int nb = min(b, k), qa = k - nb;
+    const int nb = min(b, k), qa = k - nb, count = nb * NF;
     const double* row = band_at<NF>(lu, k, qa) + wv * NF;
+    const double* dptr = lu.dinv + ((size_t)k * NF + tc) * NF;
+    double d[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) d[m] = dptr[m];
+    const double bk = y[(size_t)k * NF + wv];
+    const int rb = qa % R;
     double acc = 0.0;
-    for (int idx = lane; idx < nb * NF; idx += kWave) {
-      const int qo = idx / NF, jj = idx - qo * NF;
-      acc += row[(size_t)qo * BB + jj] * ring[((qa + qo) % R) * NF + jj];
+    for (int base = 0; base < count; base += U * kWave) {
+      double w[U];
+      band_row_load<NF>(row, count, base, lane, w);
+      acc += band_row_mac<NF>(w, ring, count, base, rb, R, lane);
     }
     acc = wave_sum(acc);
-    if (lane == kWave - 1) st[wv] = rhs[(size_t)lu.lu_node[k] * NF + wv] - acc;
+    if (lane == kWave - 1) st[wv] = bk - acc;
     __syncthreads();
     if (t < NF) {
-      const double* d = lu.dinv + ((size_t)k * NF + t) * NF;
-      double v = 0.0;
+      double r = 0.0;
 #pragma unroll
-      for (int m = 0; m < NF; ++m) v += d[m] * st[m];
-      ring[(k % R) * NF + t] = v;
-      y[(size_t)k * NF + t] = v;
+      for (int m = 0; m < NF; ++m) r += d[m] * st[m];
+      ring[(k % R) * NF + t] = r;
+      y[(size_t)k * NF + t] = r;
     }
     __syncthreads();
   }
   // backward: x_k = y_k - D_k^-1 sum_{q>k} A_kq x_q
   for (int k = n - 1; k >= 0; --k) {
-    const int nb = min(b, n - 1 - k);
+    const int nb = min(b, n - 1 - k), count = nb * NF;
     const double* row = band_at<NF>(lu, k, k + 1) + wv * NF;
+    const double* dptr = lu.dinv + ((size_t)k * NF + tc) * NF;
+    double d[NF];
+#pragma unroll
+    for (int m = 0; m < NF; ++m) d[m] = dptr[m];
+    const double yk = y[(size_t)k * NF + tc];
+    const int node = lu.lu_node[k];
+    const int rb = (k + 1) % R;
     double acc = 0.0;
-    for (int idx = lane; idx < nb * NF; idx += kWave) {
-      const int qo = idx / NF, jj = idx - qo * NF;
-      acc += row[(size_t)qo * BB + jj] * ring[((k + 1 + qo) % R) * NF + jj];
+    for (int base = 0; base < count; base += U * kWave) {
+      double w[U];
+      band_row_load<NF>(row, count, base, lane, w);
+      acc += band_row_mac<NF>(w, ring, count, base, rb, R, lane);
     }
     acc = wave_sum(acc);
     if (lane == kWave - 1) st[wv] = acc;
     __syncthreads();
     if (t < NF) {
-      const double* d = lu.dinv + ((size_t)k * NF + t) * NF;
-      double v = y[(size_t)k * NF + t];
+      double r = yk;
 #pragma unroll
-      for (int m = 0; m < NF; ++m) v -= d[m] * st[m];
-      ring[(k % R) * NF + t] = v;
-      x[(size_t)lu.lu_node[k] * NF + t] = v;
+      for (int m = 0; m < NF; ++m) r -= d[m] * st[m];
+      ring[(k % R) * NF + t] = r;
+      x[(size_t)node * NF + t] = r;
     }
     __syncthreads();
   }
