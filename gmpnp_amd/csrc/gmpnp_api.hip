@@ -1020,6 +1020,7 @@ int gmpnp_set_model(gmpnp_solver* s, const gmpnp_model_t* model) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
   int rc = check_model(model, s->dim); if (rc) return rc;
   if (model->n_species + 1 != s->nf) return fail(GMPNP_ERR_INVALID, "n_species cannot change after create");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->model = *model;
   HIP_TRY(hipMemcpy(s->d_model.p, &s->model, sizeof(gmpnp_model_t), hipMemcpyHostToDevice));
@@ -1054,6 +1055,7 @@ int gmpnp_set_supg(gmpnp_solver* s, const double* rho, const int32_t* w_index) {
 
 int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values) {
   if (!s || n < 0 || (n > 0 && (!dofs || !values))) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   std::fill(s->h_bcflag.begin(), s->h_bcflag.end(), 0);
   std::fill(s->h_bcval.begin(), s->h_bcval.end(), 0.0);
   for (int64_t k = 0; k < n; ++k) {
@@ -1071,6 +1073,7 @@ int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const d
 
 int gmpnp_set_state(gmpnp_solver* s, const double* u, const double* u_n) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   HIP_TRY(hipStreamSynchronize(s->stream));
   if (u) { int rc = upload_vec(s, u, s->u.p); if (rc) return rc; s->state_jumped = true; }
   if (u_n) { int rc = upload_vec(s, u_n, s->un.p); if (rc) return rc; }
@@ -1080,6 +1083,7 @@ int gmpnp_set_state(gmpnp_solver* s, const double* u, const double* u_n) {
 
 int gmpnp_get_state(gmpnp_solver* s, double* u_out, double* u_n_out) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   if (u_out) { int rc = download_vec(s, s->u.p, u_out); if (rc) return rc; }
   if (u_n_out) { int rc = download_vec(s, s->un.p, u_n_out); if (rc) return rc; }
   return GMPNP_OK;
@@ -1087,6 +1091,7 @@ int gmpnp_get_state(gmpnp_solver* s, double* u_out, double* u_n_out) {
 
 int gmpnp_assign_previous(gmpnp_solver* s) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   HIP_TRY(hipMemcpyAsync(s->un.p, s->u.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return GMPNP_OK;
@@ -1136,6 +1141,7 @@ int gmpnp_assemble(gmpnp_solver* s, int32_t want_jacobian, double* F_out, double
 int gmpnp_get_jacobian_csr(gmpnp_solver* s, int32_t* indptr, int32_t* indices, double* data) {
   if (!s || !indptr || !indices || !data) return fail(GMPNP_ERR_INVALID, "NULL argument");
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   const Topology& t = s->t; const int nf = s->nf;
   std::vector<double> v((size_t)t.slice_off[t.nslices]);
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1360,6 +1366,8 @@ int gmpnp_debug_occupancy(int* out4) {
 
 // debug only (not declared in gmpnp.h): raw device buffers, internal order
 int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
+  if (!s || !out) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
   const double* src = nullptr; int64_t cap = 0;
   switch (which) {
     case 0: src = s->krhat.p; cap = s->ndof; break;

@@ -219,13 +219,17 @@ def test_band_lu_is_3d_only(edl1, gpu_lib):
     assert gpu_lib.newton_options(BAND_09, dim=1).linear_solver == gpu_lib.LINEAR_BLOCK_TRIDIAGONAL
 
 
-def test_newton_with_band_lu_matches_golden(gpu_lib):
-    """'mumps' read literally: every Newton system solved by the direct solver; same iterates as the golden steps."""
+@pytest.mark.parametrize("case,L,nsteps", [("pore10", 10e-9, 2), ("pore50", 50e-9, 1)])
+def test_newton_with_band_lu_matches_golden(case, L, nsteps, gpu_lib, monkeypatch):
+    """'mumps' read literally: every Newton system solved by the direct solver; same iterates as the golden steps
+    (pore50 = the north-star mesh, selected there through GMPNP_3D_DIRECT=1 and the reference's own parameter dict)."""
     from gmpnp_amd.pore3d import PoreRun
-    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
-    run = PoreRun(num_steps=2, concentration_elec=0.5, L=10e-9, R=5e-9, solver_parameters=BAND_09)
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    if case == "pore50":
+        monkeypatch.setenv("GMPNP_3D_DIRECT", "1")
+    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=L, R=5e-9, solver_parameters=BAND_09 if case == "pore10" else None)
     try:
-        for k in range(2):
+        for k in range(nsteps):
             st = run.step(verbose=False)
             assert st["direct_solves"] == st["iterations"] == int(g["newton_its"][k]) and st["krylov_iterations"] == 0
             assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
