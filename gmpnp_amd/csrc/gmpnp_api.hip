@@ -1,6 +1,7 @@
 // C ABI of libgmpnp.so (include/gmpnp.h): handle, host drivers of assembly, preconditioner setup,
 // BiCGStab and the damped Newton loop ([3P] dolfin::NewtonSolver semantics).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -81,6 +82,8 @@ struct gmpnp_solver {
   std::vector<uint8_t> h_bcflag; std::vector<double> h_bcval;
   // pinned read-back areas
   KrylovScalars* h_scal = nullptr; double* h_part = nullptr; int32_t* h_status = nullptr;
+  HostPoll* h_poll = nullptr;   // progress mirror the B kernels write (fine-grained pinned memory)
+  int host_poll = 1;            // GMPNP_HOST_POLL=0: poll with a device-to-host copy + event per burst instead
   // Krylov graph (one per preconditioner mode)
   int graph_iters = 2;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped);
                         // measured on the bench: 1 -> 453, 2 -> 463, 4 -> 456, 8 -> 436 Newton its/s
@@ -124,6 +127,7 @@ struct gmpnp_solver {
     for (auto& e : ev_phase) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_poll) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
+    if (h_poll) (void)hipHostFree(h_poll);
     if (h_part) (void)hipHostFree(h_part);
     if (h_status) (void)hipHostFree(h_status);
     if (stream) (void)hipStreamDestroy(stream);
@@ -357,6 +361,10 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   // slot is rewritten by the next solve only, which starts after this one's final read-back
   s->h_scal[2] = init;
   HIP_TRY(hipMemcpyAsync(s->scal.p, &s->h_scal[2], sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
+  // the previous solve wrote its verdict before the host left its loop and nothing of it writes the mirror afterwards
+  volatile HostPoll* hp = s->h_poll;
+  hp->done = 0; hp->iters = 0; hp->rr = 0.0;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
   const int B = s->graph_iters;
   // Bursts of B iterations.  The first burst is 3/4 of what the previous solve with this preconditioner
   // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
@@ -379,7 +387,28 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   if (!res.done) {
     int rc = burst(first); if (rc) return rc;
     launched = first;
-    while (true) {
+    bool mirror_ok = s->host_poll != 0;
+    while (mirror_ok) {
+      // The B kernels report progress straight into pinned host memory: launch the next burst, then spin until the
+      // iterations launched BEFORE it are done (or the solve is).  No copy kernel and no event in the stream.
+      const int target = launched;
+      rc = burst(B); if (rc) return rc;
+      launched += B;
+      const double t_spin = now_ms();
+      int spins = 0;
+      while (!hp->done && hp->iters < target) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) == 0 && now_ms() - t_spin > 5000.0) { mirror_ok = false; break; }  // GPU stuck or mirror not visible
+      }
+      if (!mirror_ok) break;
+      if (hp->done) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        res.done = hp->done; res.iters = hp->iters; res.rr = hp->rr;
+        break;
+      }
+      if (launched > maxit + 4 * B) { mirror_ok = false; break; }  // defensive: the device test ends the loop at max_iters
+    }
+    while (!mirror_ok) {
       HIP_TRY(hipMemcpyAsync(&s->h_scal[slot], s->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(hipEventRecord(s->ev_poll[slot], s->stream));
       rc = burst(B); if (rc) return rc;  // speculative: overlaps the read-back
@@ -961,6 +990,10 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->part_f.alloc((size_t)3 * s->n_resblocks));
   HIP_TRY(s->scal.alloc(1)); HIP_TRY(s->status.alloc(1));
   HIP_TRY(hipHostMalloc((void**)&s->h_scal, 3 * sizeof(KrylovScalars)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_poll, 64, hipHostMallocCoherent | hipHostMallocMapped));
+  std::memset(s->h_poll, 0, 64);
+  { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, s->h_poll, 0)); s->c.poll = (HostPoll*)dp; }
+  if (const char* pl = std::getenv("GMPNP_HOST_POLL")) s->host_poll = std::atoi(pl);
   for (auto& e : s->ev_poll) HIP_TRY(hipEventCreate(&e));
   if (const char* gi = std::getenv("GMPNP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::atoi(gi));
   if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));

@@ -51,6 +51,14 @@ struct KrylovScalars {
   int32_t pad_;
 };
 
+// Progress of the running BiCGStab solve in PINNED HOST memory (fine-grained): the B kernels write it with system-scope
+// stores and the host reads it in a spin loop, instead of a device-to-host copy plus an event per polling burst.
+struct HostPoll {
+  double rr;      // ||r||^2 at the stopping test (valid once done != 0)
+  int32_t iters;  // completed iterations (every B launch)
+  int32_t done;   // exit code, written last
+};
+
 // Everything a Krylov workgroup needs to know about its tile (= one SELL slice), fetched with ONE load.
 struct TileRec {
   int64_t slice_off;  // first value of the slice in vals / vals_s
@@ -152,6 +160,7 @@ struct Ctx {
   KrylovScalars* scal;
   int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse, bit 3: hand-over timeout)
   uint32_t* ticket; // fused launch form: coarse workgroups finished so far in this solve
+  HostPoll* poll;   // host-visible progress of the solve (pinned memory, device pointer)
   const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722
   int32_t supg_w[GMPNP_MAX_SPECIES];  // species whose gradient enters species i's strong residual (identity except Q7)
 };

@@ -1047,6 +1047,14 @@ __device__ __forceinline__ void publish_ticket(const Ctx& c, unsigned seq, int g
     if (threadIdx.x == 0) __hip_atomic_store(c.ticket + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// progress / verdict for the host's spin loop (HostPoll): write-through to system memory, no fence
+__device__ __forceinline__ void poll_store(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void poll_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// end of the solve: rr and iters first, the exit code behind a system-scope release (once per solve)
+__device__ __forceinline__ void poll_finish(const Ctx& c, double rr, int iters, int done) {
+  poll_store(&c.poll->rr, rr); poll_store(&c.poll->iters, iters);
+  __hip_atomic_store(&c.poll->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
   __shared__ int ticket_ok;
   if (threadIdx.x < 64) {
@@ -1060,7 +1068,7 @@ __device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
       // 2 s at 100 MHz.  The flags cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
       // budget only has to outlast a time slice taken by another process sharing the GPU.  Ends the solve (later
       // launches exit at once).
-      if (wall_clock64() - t0 > 200000000ull) { ok = 0; if (lane == 0) { atomicOr(c.status, 8); c.scal->done = 3; } break; }
+      if (wall_clock64() - t0 > 200000000ull) { ok = 0; if (lane == 0) { atomicOr(c.status, 8); c.scal->done = 3; poll_finish(c, c.scal->rr, c.scal->iters, 3); } break; }
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane == 0) ticket_ok = ok;
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
   else if (rv == 0.0 || rho_new == 0.0) done = 3;
   // `done` is published by the B kernel (the launch after this one): other workgroups of THIS launch still read it
   const double alpha = done ? 0.0 : rho_new / rv;
-  if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->alpha, alpha); sc->rr = rr; store_coherent<FUSED>(&sc->done_next, (int32_t)done); }
+  if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->alpha, alpha); store_coherent<FUSED>(&sc->rr, rr); store_coherent<FUSED>(&sc->done_next, (int32_t)done); }
   if (done || !c.use_coarse) { publish_ticket<FUSED>(c, target, g); return; }
   if (t < n) {  // yc = Aci[:, g-block] (P^T s)_g, P^T s = P^T r_k - alpha P^T v_k
     double yv = 0.0, yr = 0.0;
@@ -1393,7 +1401,10 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     if (!dn) tcs.template load_values<true>(c);
   }
   if (dn) {
-    if (tile == 0 && t == 0) sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
+    if (tile == 0 && t == 0) {
+      sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
+      poll_finish(c, FUSED ? load_coherent(&sc->rr) : sc->rr, k, dn);  // the verdict of coarse_b(k) is on r_k: k iterations done
+    }
     return;
   }
   const bool uc = c.use_coarse != 0;
@@ -1439,7 +1450,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
       for (int q = 0; q < kSlicesPerTile; ++q) a0 += dpart[q][m];
       c.part_b[(size_t)m * c.ntiles + tile] = a0;
     }
-    if (tile == 0) sc->iters = k + 1;
+    if (tile == 0) { sc->iters = k + 1; poll_store(&c.poll->iters, k + 1); }
   }
 }
 
