@@ -251,8 +251,7 @@ template <int DIM, int NF>
 int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
   int rc = launch_element<DIM, NF>(s, want_j); if (rc) return rc;
   rc = launch_res_gather<DIM, NF>(s); if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+  // the partials and the status word land in pinned host memory by the kernel's own stores: no copy in the stream
   HIP_TRY(hipStreamSynchronize(s->stream));
   double acc = 0.0;
   for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
@@ -456,8 +455,7 @@ template <int NF>
 int true_residual(gmpnp_solver* s, double* rn) {
   hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
   hipLaunchKernelGGL(k_true_residual, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kb.p, (const double*)s->kt.p,
-                     s->kr.p, s->part_f.p, (int)s->ndof);
-  HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                     s->kr.p, s->c.part_f, (int)s->ndof);
   HIP_TRY(hipStreamSynchronize(s->stream));
   double acc = 0.0;
   for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
@@ -485,8 +483,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     else hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
     hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
     hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
-                       s->part_f.p, n, s->n_resblocks);
-    HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, 3 * s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                       s->c.part_f, n, s->n_resblocks);
     HIP_TRY(hipStreamSynchronize(s->stream));
     double wb = 0.0, ww = 0.0, bb = 0.0;
     for (int i = 0; i < s->n_resblocks; ++i) { wb += s->h_part[i]; ww += s->h_part[s->n_resblocks + i]; bb += s->h_part[2 * s->n_resblocks + i]; }
@@ -525,8 +522,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       if (random_shadow) {  // (rhat, r0) of the new shadow vector
         hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krand.p, (unsigned)(pass * 2654435761u), n);
         hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->krand.p, (const double*)s->kr.p,
-                           s->part_f.p, n, s->n_resblocks);
-        HIP_TRY(hipMemcpyAsync(s->h_part, s->part_f.p, s->n_resblocks * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                           s->c.part_f, n, s->n_resblocks);
         HIP_TRY(hipStreamSynchronize(s->stream));
         double wb = 0.0;
         for (int i = 0; i < s->n_resblocks; ++i) wb += s->h_part[i];
@@ -1008,8 +1004,9 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
     s->fused_half = mesh->dim == 3 && (s->t.ntiles + s->t.nagg) <= 3 * prop.multiProcessorCount;
   }
   if (const char* pl = std::getenv("GMPNP_FUSED_HALF")) s->fused_half = std::atoi(pl) != 0;
-  HIP_TRY(hipHostMalloc((void**)&s->h_part, 3 * std::max(s->n_resblocks, 1) * sizeof(double)));
-  HIP_TRY(hipHostMalloc((void**)&s->h_status, sizeof(int32_t)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_part, 3 * std::max(s->n_resblocks, 1) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+  HIP_TRY(hipHostMalloc((void**)&s->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped));
+  *s->h_status = 0;
 
   Ctx& c = s->c;
   c.nv = nv; c.nc = nc; c.ndof = ndof; c.nb = s->nb; c.nslices = t.nslices; c.ntiles = t.ntiles; c.n_work = (int)t.wl_slice.size();
@@ -1031,7 +1028,9 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
   c.cpart_v[0] = s->cpart_v0.p; c.cpart_v[1] = s->cpart_v1.p; c.cpart_t = s->cpart_t.p;
   c.ticket = s->ticket.p; c.part_a = s->part_a.p; c.part_rr = s->part_a.p + t.ntiles; c.part_b = s->part_b.p;
-  c.part_f = s->part_f.p; c.scal = s->scal.p; c.status = s->status.p;
+  { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, s->h_part, 0)); c.part_f = (double*)dp;
+    HIP_TRY(hipHostGetDevicePointer(&dp, s->h_status, 0)); c.status_host = (int32_t*)dp; }
+  c.scal = s->scal.p; c.status = s->status.p;
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;
   // the coarse inverse keeps its whole matrix in LDS: opt in to > 64 KiB of dynamic LDS

@@ -156,11 +156,12 @@ struct Ctx {
   double* part_rr;  // [ntiles]      ||r||^2 partials (A)
   double* part_a;   // [ntiles]      (rhat, v) (A)
   double* part_b;   // [4][ntiles]   (t,s) (t,t) (rhat,s) (rhat,t) (B)
-  double* part_f;   // residual-norm partials
+  double* part_f;   // residual-norm partials: PINNED HOST memory (the host sums them after the stream sync, no copy)
   KrylovScalars* scal;
   int32_t* status;  // device error flags (bit 0: 1-S<=0, bit 1: singular block, bit 2: singular coarse, bit 3: hand-over timeout)
   uint32_t* ticket; // fused launch form: coarse workgroups finished so far in this solve
   HostPoll* poll;   // host-visible progress of the solve (pinned memory, device pointer)
+  int32_t* status_host;  // pinned copy of *status, refreshed by k_res_gather (the host reads it with the residual norm)
   const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722
   int32_t supg_w[GMPNP_MAX_SPECIES];  // species whose gradient enters species i's strong residual (identity except Q7)
 };

@@ -455,7 +455,10 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
   }
   double v[1] = {val * val};
   block_sum<1>(v, lds);
-  if (threadIdx.x == 0) c.part_f[blockIdx.x] = v[0];
+  if (threadIdx.x == 0) {
+    c.part_f[blockIdx.x] = v[0];
+    if (blockIdx.x == 0) c.status_host[0] = __hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // flags of the kernels before this one
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
