@@ -343,23 +343,16 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   s->c.use_coarse = use_coarse;
   const int n = s->ndof;
-  // shadow vector: r_0, or (experiment, GMPNP_SHADOW_B=1) the original right-hand side of a warm-started solve
-  hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->krhat.p, (double*)nullptr,
-                     s->shadow_src ? s->shadow_src : s->kr.p, n);
-  HIP_TRY(hipMemsetAsync(s->ky.p, 0, n * sizeof(double), s->stream));
-  if (s->fused_half) { HIP_TRY(hipMemsetAsync(s->ticket.p, 0, 16 * 66 * sizeof(uint32_t), s->stream)); s->fused_seq = 0; }
-  if (use_coarse)  // P^T b partials where A(0) expects them
-    hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->kr.p, s->cpart_v1.p);
+  s->fused_seq = 0;
   KrylovScalars init{};
   init.rho[0] = init.rho[1] = s->shadow_src ? s->shadow_rho0 : bnorm * bnorm; init.alpha = 1.0;
   init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.iters = 0; init.it_cur = 0;
   init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
   init.rr0 = bnorm * bnorm;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
-  // the initial values travel from their own pinned slot (slots 0/1 are the read-back buffers): no host wait here; the
-  // slot is rewritten by the next solve only, which starts after this one's final read-back
-  s->h_scal[2] = init;
-  HIP_TRY(hipMemcpyAsync(s->scal.p, &s->h_scal[2], sizeof(KrylovScalars), hipMemcpyHostToDevice, s->stream));
+  // one launch: shadow vector (r_0, or GMPNP_SHADOW_B=1 / a random vector after a breakdown), y = 0, P^T r_0 partials
+  // where A(0) expects them, hand-over flags cleared, scalars from the kernel argument
+  hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->shadow_src, init, s->cpart_v1.p);
   // the previous solve wrote its verdict before the host left its loop and nothing of it writes the mirror afterwards
   volatile HostPoll* hp = s->h_poll;
   hp->done = 0; hp->iters = 0; hp->rr = 0.0;
@@ -469,10 +462,12 @@ int true_residual(gmpnp_solver* s, double* rn) {
 // same absolute target is reached in far fewer iterations.  Falls back to x0 = 0 when x0 does not reduce the residual.
 template <int NF>
 int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st,
-                    int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0) {
+                    int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0, const double* rhs_src = nullptr) {
   const int n = s->ndof;
   const double tol = std::max(rtol * bnorm, atol);
-  HIP_TRY(hipMemcpyAsync(s->kb.p, s->kr.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  // kb keeps the right-hand side; `rhs_src` (Newton: F) saves the caller's separate copy into kr
+  if (rhs_src) hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kr.p, s->kb.p, rhs_src, n);
+  else HIP_TRY(hipMemcpyAsync(s->kb.p, s->kr.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   gmpnp_linear_stats_t total{}; total.rhs_norm = bnorm;
   double rhs_norm = bnorm;
   bool warm = false;
@@ -767,8 +762,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       const bool coarse_fresh = s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || s->state_jumped || s->coarse_refresh_due;
       rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, s->precond_lag <= 1 || (st.iterations % s->precond_lag) == 0,
                                          coarse_fresh); if (rc) return rc;
-      // rhs = b (current residual vector F)
-      HIP_TRY(hipMemcpyAsync(s->kr.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+      // rhs = b (current residual vector F): copied into kr and kb by krylov_verified
       HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       gmpnp_linear_stats_t ls{};
       // inside Newton only long solves are checked: a short one does not drift, and Newton's own residual test sees
@@ -784,7 +778,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // solution moves smoothly in time, but the residual of a new step is not dominated by that motion.
       else if (s->warm_start > 2 && st.iterations == 0 && s->have_step) { wa = 1.0; wb = -1e301; }
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
-                               o.krylov_maximum_iterations, &ls, 500, wa, wb);
+                               o.krylov_maximum_iterations, &ls, 500, wa, wb, s->F.p);
       // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
       if (st.iterations < 32) s->hint_by_newton_it[st.iterations] = ls.iterations;
       s->krylov_hint = 0;

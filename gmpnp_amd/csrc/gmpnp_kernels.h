@@ -1677,6 +1677,39 @@ __global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, dou
   if (i < n) y[i] += a * x[i];
 }
 
+// Start of a BiCGStab solve in ONE launch (was: copy, two memsets, k_restrict and a host-to-device copy of the scalars):
+// rhat = shadow vector (r_0 unless given), y = 0, restriction partials of r_0 where A(0) expects them, hand-over flags
+// cleared, scalars set from the kernel argument.  One workgroup per tile, as k_restrict.
+template <int NF>
+__global__ __launch_bounds__(kVecBlock) void k_krylov_init(const Ctx c, const double* __restrict__ shadow, const KrylovScalars init,
+                                                           double* __restrict__ part) {
+  __shared__ double lv[kSlicesPerTile * 64];
+  const int tile = blockIdx.x, t = threadIdx.x;
+  if (t < kSlicesPerTile * 64) {
+    const int sl = t >> 6, lane = t & 63, s = c.tile_slice0[tile] + sl;
+    const int Iloc = lane / NF, i = lane - Iloc * NF;
+    const bool active = s < c.tile_slice0[tile + 1] && Iloc < c.slice_nn[s] && Iloc < kWave / NF;
+    double v = 0.0;
+    if (active) {
+      const int idx = (c.slice_node0[s] + Iloc) * NF + i;
+      v = c.kr[idx];
+      c.krhat[idx] = shadow ? shadow[idx] : v;
+      c.ky[idx] = 0.0;
+    }
+    lv[t] = v;
+  }
+  if (tile == 0) {
+    for (int q = t; q < 16 * 66; q += kVecBlock) c.ticket[q] = 0u;
+    if (t == 0) *c.scal = init;
+  }
+  __syncthreads();
+  if (c.use_coarse && t < NF) {
+    double sacc = 0.0;
+    for (int q = 0; q < kSlicesPerTile; ++q)
+      for (int il = 0; il < kWave / NF; ++il) sacc += lv[q * 64 + il * NF + t];
+    part[(size_t)c.tile_slot[tile] * c.ncoarse + c.tile_agg[tile] * NF + t] = sacc;
+  }
+}
 __global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double v = src[i]; a[i] = v; if (b) b[i] = v; }
