@@ -16,7 +16,7 @@ import numpy as np
 from .mesh import read_dolfin_xml, resolve_mesh_path
 from .params import pore_parameters, utilities_dir
 from .problem import pore_dirichlet, pore_problem
-from .solver import GMPNPSystem, project_gradient
+from .solver import GMPNPSystem, column_medians, project_gradient
 from .vtk import write_pvd
 
 SOLVER_PARAMETERS = {  # reference 3D:789-798
@@ -67,8 +67,7 @@ class PoreRun:
         st = self.sys.solve(self.solver_parameters)
         vals = self.sys.vertex_values()
         # medians of the scaled ion concentrations -> Sechenov -> new CO2 Dirichlet value at S1 (3D:817-838)
-        co2 = self.pp.sechenov_co2_scaled(np.median(vals[:, 1]), np.median(vals[:, 2]), np.median(vals[:, 3]),
-                                          np.median(vals[:, 7]))
+        co2 = self.pp.sechenov_co2_scaled(*column_medians(vals, (1, 2, 3, 7)))
         self.co2_bc = co2
         self.sys.set_bcs(*pore_dirichlet(self.pp, self.bnd, co2))
         self.history.append(vals)

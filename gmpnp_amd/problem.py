@@ -78,9 +78,25 @@ def pore_dirichlet(pp, bnd, co2_value=None):
     ns = len(pp.species)
     co2 = pp.eq_conc_CO2_scaled if co2_value is None else co2_value
     s1, s2, s3 = bnd.dirichlet_vertices[1], bnd.dirichlet_vertices[2], bnd.dirichlet_vertices[3]
-    bcs = [(s1, ns, 0.0), (s3, ns, 0.0), (s2, ns, pp.voltage_scaled),
-           (s1, 4, co2), (s1, 5, pp.eq_conc_CO_scaled), (s1, 6, pp.eq_conc_H2_scaled)]
-    return merge_dirichlet(bcs, ns + 1)
+    # Only the CO2 value changes between time steps: the merged dof set and the positions of the bc4 entries in it are
+    # kept on the boundary record (keyed by everything else that enters), so the per-step rebuild is one fill.
+    key = (ns, float(pp.voltage_scaled), float(pp.eq_conc_CO_scaled), float(pp.eq_conc_H2_scaled))
+    cache = getattr(bnd, "_dirichlet_cache", None)
+    if cache is None or cache[0] != key:
+        bcs = [(s1, ns, 0.0), (s3, ns, 0.0), (s2, ns, pp.voltage_scaled),
+               (s1, 4, co2), (s1, 5, pp.eq_conc_CO_scaled), (s1, 6, pp.eq_conc_H2_scaled)]
+        dofs, vals = merge_dirichlet(bcs, ns + 1)
+        # field 4 appears in bc4 only, so "later bc wins" never touches these entries
+        idx = np.searchsorted(dofs, np.asarray(s1, dtype=np.int64).ravel() * (ns + 1) + 4)
+        cache = (key, dofs, vals, idx)
+        try:
+            bnd._dirichlet_cache = cache
+        except AttributeError:  # a record type without room for it: no caching
+            return dofs, vals
+    _, dofs, vals, idx = cache
+    vals = vals.copy()
+    vals[idx] = co2
+    return dofs, vals
 
 
 def pore_problem(pp, mesh: Mesh, quad: Quadrature = None, refine: int = 0):

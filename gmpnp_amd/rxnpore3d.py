@@ -25,7 +25,7 @@ from .mesh import read_dolfin_xml, resolve_mesh_path
 from .params import pore_parameters, utilities_dir
 from .pore3d import SOLVER_PARAMETERS, output_root, scale_conc_time
 from .problem import pore_dirichlet, pore_problem
-from .solver import GMPNPSystem, project_gradient
+from .solver import GMPNPSystem, column_medians, project_gradient
 from .vtk import write_pvd
 
 SOLVED = ["H", "OH", "HCO3", "CO32", "CO2", "CO", "H2"]  # the reference's MixedElement([P3]*7), :363
@@ -75,7 +75,7 @@ class RxnPoreRun:
         st = self.sys.solve(self.solver_parameters)
         vals = self.sys.vertex_values()
         b, cat = pp.bulk_conc, pp.cation
-        med = {nme: float(np.median(vals[:, i])) for i, nme in enumerate(SOLVED[:4])}
+        med = dict(zip(SOLVED[:4], (float(m) for m in column_medians(vals, range(4)))))
         # assuming electroneutrality to estimate the concentration of cations (:564-568)
         conc_cat = med["HCO3"] * b["HCO3"] + 2 * med["CO32"] * b["CO32"] + med["OH"] * b["OH"] - med["H"] * b["H"]
         co2 = pp.sechenov_co2_scaled(med["OH"], med["HCO3"], med["CO32"], conc_cat / b[cat])

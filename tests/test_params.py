@@ -117,3 +117,41 @@ def test_rxn_diff_parameters_match_reference_formulas():
     assert rp.species == ["H", "OH", "HCO3", "CO32", "CO2", "K"] and m.rc1[5].tolist() == [0.0] * 6  # cation: no source
     with pytest.raises(UnboundLocalError):
         rxn_diff_parameters(L_n=20e-6)  # no mesh for 20 um: the reference leaves mesh_number unbound
+
+
+def test_column_medians_equals_numpy_median():
+    """The per-step medians of the 3D driver (reference 3D:817-824) use one selection pass; values are np.median's."""
+    from gmpnp_amd.solver import column_medians
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 10, 3679, 3680):
+        v = rng.standard_normal((n, 9))
+        assert np.array_equal(column_medians(v, (1, 2, 3, 7)), np.array([np.median(v[:, c]) for c in (1, 2, 3, 7)]))
+    v[5, 2] = np.nan
+    m = column_medians(v, (1, 2, 3, 7))
+    assert np.isnan(m[1]) and not np.isnan(m[0])
+
+
+def test_pore_dirichlet_cache_equals_a_fresh_merge(pore10):
+    """bc4 is rebuilt every time step (reference 3D:835-838); the cached dof set must give what DOLFIN's in-order
+    application gives for any CO2 value, and must notice a changed wall potential (sweep continuation)."""
+    import copy
+    from gmpnp_amd.problem import merge_dirichlet, pore_dirichlet
+    pp, _, _, bnd = pore10
+    pp = copy.copy(pp)
+
+    def fresh(co2):
+        s1, s2, s3 = bnd.dirichlet_vertices[1], bnd.dirichlet_vertices[2], bnd.dirichlet_vertices[3]
+        ns = len(pp.species)
+        return merge_dirichlet([(s1, ns, 0.0), (s3, ns, 0.0), (s2, ns, pp.voltage_scaled), (s1, 4, co2),
+                                (s1, 5, pp.eq_conc_CO_scaled), (s1, 6, pp.eq_conc_H2_scaled)], ns + 1)
+
+    for co2 in (5.7, 4.2, 5.7):
+        d, v = pore_dirichlet(pp, bnd, co2)
+        d0, v0 = fresh(co2)
+        assert np.array_equal(d, d0) and np.array_equal(v, v0)
+    pp.voltage_scaled = -3.0
+    d, v = pore_dirichlet(pp, bnd, 1.5)
+    d0, v0 = fresh(1.5)
+    assert np.array_equal(d, d0) and np.array_equal(v, v0)
+    v[:] = 0.0  # the caller's array is its own
+    assert np.array_equal(pore_dirichlet(pp, bnd, 1.5)[1], v0)

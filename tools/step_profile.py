@@ -7,6 +7,7 @@ import __graft_entry__ as ge
 ge.build()
 from gmpnp_amd.pore3d import PoreRun
 from gmpnp_amd.problem import pore_dirichlet
+from gmpnp_amd.solver import column_medians
 run = PoreRun(num_steps=20, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"use_graph": False})
 T = {}
 def tic(name, t0):
@@ -16,7 +17,7 @@ for n in range(20):
     T["gpu_total_ms"] = T.get("gpu_total_ms", 0.0) + st["ms_total"]
     T["newton"] = T.get("newton", 0) + st["iterations"]
     t0 = time.perf_counter(); vals = run.sys.vertex_values(); tic("vertex_values", t0)
-    t0 = time.perf_counter(); co2 = run.pp.sechenov_co2_scaled(np.median(vals[:, 1]), np.median(vals[:, 2]), np.median(vals[:, 3]), np.median(vals[:, 7])); tic("median+sechenov", t0)
+    t0 = time.perf_counter(); co2 = run.pp.sechenov_co2_scaled(*column_medians(vals, (1, 2, 3, 7))); tic("median+sechenov", t0)
     t0 = time.perf_counter(); d, v = pore_dirichlet(run.pp, run.bnd, co2); tic("pore_dirichlet", t0)
     t0 = time.perf_counter(); run.sys.set_bcs(d, v); tic("set_bcs", t0)
     t0 = time.perf_counter(); run.sys.assign_previous(); tic("assign_previous", t0)
