@@ -85,8 +85,9 @@ struct gmpnp_solver {
   HostPoll* h_poll = nullptr;   // progress mirror the B kernels write (fine-grained pinned memory)
   int host_poll = 1;            // GMPNP_HOST_POLL=0: poll with a device-to-host copy + event per burst instead
   // Krylov graph (one per preconditioner mode)
-  int graph_iters = 2;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped);
-                        // measured on the bench: 1 -> 453, 2 -> 463, 4 -> 456, 8 -> 436 Newton its/s
+  int graph_iters = 1;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped);
+                        // with copy + event polling: 1 -> 453, 2 -> 463, 4 -> 456, 8 -> 436 Newton its/s; with the pinned
+                        // progress mirror a poll costs nothing on the device: 1 -> 496, 2 -> 492
   int krylov_hint = 0;  // expected iterations of the next solve (the same Newton iteration of the previous time step), 0 = none
   int hint_by_newton_it[32] = {0};
   int last_krylov_iters[2] = {0, 0};
@@ -365,7 +366,8 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   // first burst: 7/8 of the count the same Newton iteration needed one time step ago (solves of one index resemble each
   // other far more than consecutive solves do: the first of a step is cold, the others are warm-started), else 3/4 of
   // the previous solve
-  const int expect = s->krylov_hint > 0 ? (7 * s->krylov_hint) / 8 : (3 * s->last_krylov_iters[use_coarse]) / 4;
+  static const int hint16 = std::getenv("GMPNP_HINT_FRAC16") ? std::atoi(std::getenv("GMPNP_HINT_FRAC16")) : 14;
+  const int expect = s->krylov_hint > 0 ? (hint16 * s->krylov_hint) / 16 : (3 * s->last_krylov_iters[use_coarse]) / 4;
   int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, expect);
   if (restart) first = B;  // a restart pass only has to remove the drift
   first = ((first + B - 1) / B) * B;
