@@ -115,6 +115,7 @@ struct gmpnp_solver {
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
   // block-banded LU (3D): direct solver / fallback of the Krylov solve; storage is allocated on first use
   DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
+  bool phase_timing = false;  // GMPNP_PHASE_TIMING=1 fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
   int direct_fallback = 1;      // GMPNP_DIRECT_FALLBACK=0: a failed Krylov solve is an error again
   double lu_max_gb = 48.0;      // GMPNP_BAND_LU_MAX_GB: largest band storage the fallback may allocate
   int direct_solves = 0;        // band LU solves since create (factorisations)
@@ -736,12 +737,12 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
   bool done = conv(r);
   if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual is NaN before the first Newton iteration");
   while (!done && st.iterations < o.maximum_iterations) {
-    HIP_TRY(hipEventRecord(s->ev_phase[0], s->stream));
+    if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[0], s->stream));
     rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc;   // element records: left by the last residual evaluation
     s->jacobian_valid = true;
-    HIP_TRY(hipEventRecord(s->ev_phase[1], s->stream));
+    if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[1], s->stream));
     if (o.linear_solver == GMPNP_LINEAR_BLOCK_TRIDIAGONAL) {
-      HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+      if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       if constexpr (DIM == 1) {
         rc = tri_solve<NF>(s, s->F.p); if (rc) return rc;
         rc = tri_apply<NF>(s, s->u.p, 1.0, -o.relaxation_parameter); if (rc) return rc;
@@ -751,7 +752,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     } else if (o.linear_solver == GMPNP_LINEAR_BAND_LU || s->direct_sticky > 0) {
       if constexpr (DIM == 3) {
         HIP_TRY(hipMemcpyAsync(s->kb.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-        HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+        if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
         gmpnp_linear_stats_t ls{};
         rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ls); if (rc) return rc;
         st.direct_solves++;
@@ -767,7 +768,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, s->precond_lag <= 1 || (st.iterations % s->precond_lag) == 0,
                                          coarse_fresh); if (rc) return rc;
       // rhs = b (current residual vector F): copied into kr and kb by krylov_verified
-      HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
+      if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       gmpnp_linear_stats_t ls{};
       // inside Newton only long solves are checked: a short one does not drift, and Newton's own residual test sees
       // whatever is left
@@ -817,20 +818,22 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
                          -o.relaxation_parameter, (int)s->ndof);
     }
-    HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
+    if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
     st.iterations++;
     ta = now_ms();
     rc = residual<DIM, NF>(s, true, &r, &flags); if (rc) return rc;  // synchronises the stream
-    float ms01 = 0.f, ms12 = 0.f, ms23 = 0.f, ms3 = 0.f;
-    (void)hipEventElapsedTime(&ms01, s->ev_phase[0], s->ev_phase[1]);
-    (void)hipEventElapsedTime(&ms12, s->ev_phase[1], s->ev_phase[2]);
-    (void)hipEventElapsedTime(&ms23, s->ev_phase[2], s->ev_phase[3]);
-    HIP_TRY(hipEventRecord(s->ev_phase[4], s->stream));
-    HIP_TRY(hipEventSynchronize(s->ev_phase[4]));
-    (void)hipEventElapsedTime(&ms3, s->ev_phase[3], s->ev_phase[4]);
-    st.ms_assemble += ms01 + ms3;   // Jacobian assembly + next residual (device time)
-    st.ms_setup += ms12;
-    st.ms_krylov += ms23;
+    if (s->phase_timing) {  // GMPNP_PHASE_TIMING=1: device time per phase (five event records and one more wait per iteration)
+      float ms01 = 0.f, ms12 = 0.f, ms23 = 0.f, ms3 = 0.f;
+      (void)hipEventElapsedTime(&ms01, s->ev_phase[0], s->ev_phase[1]);
+      (void)hipEventElapsedTime(&ms12, s->ev_phase[1], s->ev_phase[2]);
+      (void)hipEventElapsedTime(&ms23, s->ev_phase[2], s->ev_phase[3]);
+      HIP_TRY(hipEventRecord(s->ev_phase[4], s->stream));
+      HIP_TRY(hipEventSynchronize(s->ev_phase[4]));
+      (void)hipEventElapsedTime(&ms3, s->ev_phase[3], s->ev_phase[4]);
+      st.ms_assemble += ms01 + ms3;   // Jacobian assembly + next residual (device time)
+      st.ms_setup += ms12;
+      st.ms_krylov += ms23;
+    }
     if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
     if (flags & 14) return fail(GMPNP_ERR_LINEAR, status_message(flags));
     if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
@@ -994,6 +997,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   if (const char* pl = std::getenv("GMPNP_COARSE_LAG")) s->coarse_lag = std::max(1, std::atoi(pl));
   if (const char* pl = std::getenv("GMPNP_WARM_START")) s->warm_start = std::atoi(pl);
   if (const char* pl = std::getenv("GMPNP_DIRECT_FALLBACK")) s->direct_fallback = std::atoi(pl);
+  if (const char* pl = std::getenv("GMPNP_PHASE_TIMING")) s->phase_timing = std::atoi(pl) != 0;
   if (const char* pl = std::getenv("GMPNP_BAND_LU_MAX_GB")) s->lu_max_gb = std::atof(pl);
   {  // fused launch form only where every workgroup of a launch is resident at once (3 x 512 threads per CU): there the
      // hand-over inside the launch beats a launch boundary (+5 % on L_50_R_5); with more tiles than slots it loses (-4 %)

@@ -124,7 +124,8 @@ typedef struct {
   int32_t n_residuals;          /* iterations + 1 */
   double residuals[GMPNP_MAX_NEWTON_HISTORY]; /* ||b||_2 before iteration 0 and after each update */
   int32_t krylov_per_iteration[GMPNP_MAX_NEWTON_HISTORY];
-  double ms_assemble, ms_setup, ms_krylov, ms_total; /* host wall clock, ms */
+  double ms_assemble, ms_setup, ms_krylov, ms_total; /* ms_total: host wall clock of the solve; the three phases are
+                                                        device times (hipEvents), filled when GMPNP_PHASE_TIMING=1 only */
   int32_t direct_solves;        /* Newton iterations whose system the block-banded LU solved (mode 3 or fallback) */
   int32_t pad_;
 } gmpnp_newton_stats_t;

@@ -1,5 +1,6 @@
 """Exploratory GPU check (not a test): compare HIP assembly / SpMV / solves with the oracle and time them."""
 import os, sys, time
+os.environ.setdefault("GMPNP_PHASE_TIMING", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np

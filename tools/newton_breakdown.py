@@ -1,6 +1,7 @@
 """Where a Newton iteration of the bench workload goes: device time of assembly / preconditioner set-up / Krylov
 (hipEvents inside gmpnp_newton_solve) against the wall clock of the solve and of the whole time step (GPU box)."""
 import os, sys, time
+os.environ.setdefault("GMPNP_PHASE_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gmpnp_amd.pore3d import PoreRun
 
