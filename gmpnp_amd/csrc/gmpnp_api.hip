@@ -248,6 +248,8 @@ int launch_jac_gather(gmpnp_solver* s) {
   return GMPNP_OK;
 }
 
+int drain_spmv_events(gmpnp_solver* s);
+
 // residual at the current u: returns ||b||_2 and the device status flags
 template <int DIM, int NF>
 int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
@@ -255,6 +257,7 @@ int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
   rc = launch_res_gather<DIM, NF>(s); if (rc) return rc;
   // the partials and the status word land in pinned host memory by the kernel's own stores: no copy in the stream
   HIP_TRY(hipStreamSynchronize(s->stream));
+  rc = drain_spmv_events(s); if (rc) return rc;
   double acc = 0.0;
   for (int i = 0; i < s->n_resblocks; ++i) acc += s->h_part[i];
   *norm = std::sqrt(acc);
@@ -414,8 +417,8 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
       if (res.done) break;
       if (launched > maxit + 4 * B) break;  // defensive: the device test ends the loop at max_iters
     }
-    if (s->ev_used) HIP_TRY(hipStreamSynchronize(s->stream));
-    rc = drain_spmv_events(s); if (rc) return rc;
+    // the sampled launches' events are read at the next point where the stream is synchronised anyway (residual(),
+    // the end of gmpnp_linear_solve, gmpnp_spmv_profile): no wait of its own
   }
   if (!restart) s->last_krylov_iters[use_coarse] = res.iters;
   s->last_done = res.done;
@@ -1249,6 +1252,8 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   GMPNP_DISPATCH(s, rc = (krylov_verified<NF>(s, mode, bn, rtol, atol, maxit, &ls)));
   if (stats) *stats = ls;
   HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  { int rc2 = drain_spmv_events(s); if (rc2) return rc2; }
   if (*s->h_status & 14) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
   if (rc) return rc;
   return download_vec(s, s->kx.p, x);
@@ -1429,6 +1434,9 @@ int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
 
 int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  { int rc = drain_spmv_events(s); if (rc) return rc; }
   if (n_sampled) *n_sampled = s->spmv_sampled;
   if (mean_us) *mean_us = s->spmv_sampled ? s->spmv_us_sum / s->spmv_sampled : 0.0;
   if (n_launched) *n_launched = s->spmv_launched;
