@@ -79,7 +79,9 @@ struct gmpnp_solver {
   DevBuf<int64_t> rob_addr, slice_off;
   DevBuf<uint8_t> bcflag, sell_aggslot;
   DevBuf<KrylovScalars> scal; DevBuf<TileRec> tile_rec;
-  std::vector<uint8_t> h_bcflag; std::vector<double> h_bcval;
+  std::vector<uint8_t> h_bcflag, h_bcflag_dev;   // flags being built / flags the device holds
+  double* h_bcval = nullptr;    // pinned [ndof]
+  double* h_stage = nullptr;    // pinned [ndof]: staging of the file-order <-> internal-order vector transfers
   // pinned read-back areas
   KrylovScalars* h_scal = nullptr; double* h_part = nullptr; int32_t* h_status = nullptr;
   HostPoll* h_poll = nullptr;   // progress mirror the B kernels write (fine-grained pinned memory)
@@ -130,6 +132,8 @@ struct gmpnp_solver {
     for (auto& e : ev_poll) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
     if (h_poll) (void)hipHostFree(h_poll);
+    if (h_bcval) (void)hipHostFree(h_bcval);
+    if (h_stage) (void)hipHostFree(h_stage);
     if (h_part) (void)hipHostFree(h_part);
     if (h_status) (void)hipHostFree(h_status);
     if (stream) (void)hipStreamDestroy(stream);
@@ -856,28 +860,20 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
   return GMPNP_OK;
 }
 
-void to_internal(const gmpnp_solver* s, const double* src, std::vector<double>& dst) {
-  const int nf = s->nf, nv = s->t.nv;
-  dst.resize((size_t)nv * nf);
-  for (int i = 0; i < nv; ++i) std::memcpy(&dst[(size_t)i * nf], &src[(size_t)s->t.perm[i] * nf], nf * sizeof(double));
-}
-
-void to_file(const gmpnp_solver* s, const std::vector<double>& src, double* dst) {
-  const int nf = s->nf, nv = s->t.nv;
-  for (int i = 0; i < nv; ++i) std::memcpy(&dst[(size_t)s->t.perm[i] * nf], &src[(size_t)i * nf], nf * sizeof(double));
-}
-
 int upload_vec(gmpnp_solver* s, const double* file_order, double* dev) {
-  std::vector<double> tmp; to_internal(s, file_order, tmp);
-  HIP_TRY(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  const int nf = s->nf, nv = s->t.nv;
+  HIP_TRY(hipStreamSynchronize(s->stream));   // the staging buffer is free again
+  for (int i = 0; i < nv; ++i) std::memcpy(&s->h_stage[(size_t)i * nf], &file_order[(size_t)s->t.perm[i] * nf], nf * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(dev, s->h_stage, (size_t)s->ndof * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return GMPNP_OK;
 }
 
 int download_vec(gmpnp_solver* s, const double* dev, double* file_order) {
-  std::vector<double> tmp((size_t)s->ndof);
+  const int nf = s->nf, nv = s->t.nv;
+  HIP_TRY(hipMemcpyAsync(s->h_stage, dev, (size_t)s->ndof * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-  to_file(s, tmp, file_order);
+  for (int i = 0; i < nv; ++i) std::memcpy(&file_order[(size_t)s->t.perm[i] * nf], &s->h_stage[(size_t)i * nf], nf * sizeof(double));
   return GMPNP_OK;
 }
 
@@ -956,8 +952,11 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->d_model.upload(mv)); HIP_TRY(s->d_quad.upload(qv));
   HIP_TRY(s->coords.upload(t.coords)); HIP_TRY(s->cells.upload(t.cells));
   HIP_TRY(s->u.alloc(ndof)); HIP_TRY(s->un.alloc(ndof)); HIP_TRY(s->F.alloc(ndof));
-  s->h_bcflag.assign(ndof, 0); s->h_bcval.assign(ndof, 0.0);
-  HIP_TRY(s->bcflag.upload(s->h_bcflag)); HIP_TRY(s->bcval.upload(s->h_bcval));
+  s->h_bcflag.assign(ndof, 0); s->h_bcflag_dev.assign(ndof, 0);
+  HIP_TRY(hipHostMalloc((void**)&s->h_bcval, (size_t)ndof * sizeof(double)));
+  HIP_TRY(hipHostMalloc((void**)&s->h_stage, (size_t)ndof * sizeof(double)));
+  std::memset(s->h_bcval, 0, (size_t)ndof * sizeof(double));
+  HIP_TRY(s->bcflag.upload(s->h_bcflag)); HIP_TRY(s->bcval.alloc(ndof));
   HIP_TRY(s->EF.alloc((size_t)nc * nn * nf)); HIP_TRY(s->EJ.alloc((size_t)nc * ej_stride));
   HIP_TRY(s->n2e_ptr.upload(t.n2e_ptr)); HIP_TRY(s->n2e.upload(t.n2e));
   HIP_TRY(s->rowptr.upload(t.rowptr)); HIP_TRY(s->cols.upload(t.cols));
@@ -1093,17 +1092,21 @@ int gmpnp_set_supg(gmpnp_solver* s, const double* rho, const int32_t* w_index) {
 int gmpnp_set_dirichlet(gmpnp_solver* s, int64_t n, const int64_t* dofs, const double* values) {
   if (!s || n < 0 || (n > 0 && (!dofs || !values))) return fail(GMPNP_ERR_INVALID, "bad arguments");
   HIP_TRY(hipSetDevice(s->opts.device_id));
+  HIP_TRY(hipStreamSynchronize(s->stream));   // the pinned value buffer may still be in flight
   std::fill(s->h_bcflag.begin(), s->h_bcflag.end(), 0);
-  std::fill(s->h_bcval.begin(), s->h_bcval.end(), 0.0);
+  std::memset(s->h_bcval, 0, (size_t)s->ndof * sizeof(double));
   for (int64_t k = 0; k < n; ++k) {
     const int64_t d = dofs[k];
     if (d < 0 || d >= s->ndof) return fail(GMPNP_ERR_INVALID, "Dirichlet dof out of range");
     const int r = s->t.iperm[d / s->nf] * s->nf + (int)(d % s->nf);
     s->h_bcflag[r] = 1; s->h_bcval[r] = values[k];
   }
+  if (s->h_bcflag != s->h_bcflag_dev) {  // the dof SET rarely changes (3D: only the CO2 value moves between time steps)
+    HIP_TRY(hipMemcpy(s->bcflag.p, s->h_bcflag.data(), s->ndof, hipMemcpyHostToDevice));
+    s->h_bcflag_dev = s->h_bcflag;
+  }
+  HIP_TRY(hipMemcpyAsync(s->bcval.p, s->h_bcval, s->ndof * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(s->bcflag.p, s->h_bcflag.data(), s->ndof, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(s->bcval.p, s->h_bcval.data(), s->ndof * sizeof(double), hipMemcpyHostToDevice));
   s->jacobian_valid = false;
   return GMPNP_OK;
 }
@@ -1129,8 +1132,8 @@ int gmpnp_get_state(gmpnp_solver* s, double* u_out, double* u_n_out) {
 int gmpnp_assign_previous(gmpnp_solver* s) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(s->opts.device_id));
+  // stream-ordered: whatever reads u_n next is launched behind this copy, and every read-back synchronises the stream
   HIP_TRY(hipMemcpyAsync(s->un.p, s->u.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
   return GMPNP_OK;
 }
 
