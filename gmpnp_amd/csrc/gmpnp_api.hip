@@ -117,6 +117,7 @@ struct gmpnp_solver {
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
   // block-banded LU (3D): direct solver / fallback of the Krylov solve; storage is allocated on first use
   DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
+  bool x0_predicted = false;  // kx holds the predicted start of the next linear solve (left by the previous Newton update)
   bool phase_timing = false;  // GMPNP_PHASE_TIMING=1 fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
   int direct_fallback = 1;      // GMPNP_DIRECT_FALLBACK=0: a failed Krylov solve is an error again
   double lu_max_gb = 48.0;      // GMPNP_BAND_LU_MAX_GB: largest band storage the fallback may allocate
@@ -438,12 +439,13 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
 
 // dst = scale_dst*dst + scale_x * M^{-1} src,  M^{-1} = Dinv (I + P Aci P^T)
 template <int NF>
-int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x) {
+int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x,
+               const NewtonUpdate* upd = nullptr) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   if (s->c.use_coarse)
     hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, src, s->cpart_v0.p);
   hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, src,
-                     (const double*)s->cpart_v0.p, dst, scale_dst, scale_x);
+                     (const double*)s->cpart_v0.p, dst, scale_dst, scale_x, upd ? *upd : NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0});
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
 }
@@ -472,12 +474,16 @@ int true_residual(gmpnp_solver* s, double* rn) {
 // same absolute target is reached in far fewer iterations.  Falls back to x0 = 0 when x0 does not reduce the residual.
 template <int NF>
 int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st,
-                    int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0, const double* rhs_src = nullptr) {
+                    int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0, const double* rhs_src = nullptr,
+                    bool rhs_ready = false, bool x0_ready = false, const NewtonUpdate* upd = nullptr, bool* upd_done = nullptr) {
   const int n = s->ndof;
   const double tol = std::max(rtol * bnorm, atol);
   // kb keeps the right-hand side; `rhs_src` (Newton: F) saves the caller's separate copy into kr
-  if (rhs_src) hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kr.p, s->kb.p, rhs_src, n);
+  // `rhs_ready`: k_res_gather already left b in kr and kb (Newton)
+  if (rhs_ready) {}
+  else if (rhs_src) hipLaunchKernelGGL(k_copy2, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kr.p, s->kb.p, rhs_src, n);
   else HIP_TRY(hipMemcpyAsync(s->kb.p, s->kr.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  if (upd_done) *upd_done = false;
   gmpnp_linear_stats_t total{}; total.rhs_norm = bnorm;
   double rhs_norm = bnorm;
   bool warm = false;
@@ -485,7 +491,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     // direction d = warm_scale * kx + warm_prev * kxp (warm_prev < -1e300: d = kstep, the previous time step's update);
     // x0 = theta d with theta minimising ||b - theta J d||: one plain SpMV, three dots, one host round trip
     if (warm_prev < -1e300) HIP_TRY(hipMemcpyAsync(s->kx.p, s->kstep.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    else hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
+    else if (!x0_ready) hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
     hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
     hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
                        s->c.part_f, n, s->n_resblocks);
@@ -541,7 +547,11 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     if (rc && rc != GMPNP_ERR_LINEAR) { if (st) *st = total; return rc; }
     const bool usable = (s->last_done == 1 || s->last_done == 2);  // converged or cap reached: y is a valid partial solution
     if (usable && ls.iterations > 0) {
-      int rc2 = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, have_x ? 1.0 : 0.0, 1.0); if (rc2) return rc2;
+      // the normal end of a solve inside Newton (first pass, converged, short enough to go unchecked): the final
+      // M^-1 application also applies the Newton update and leaves the predicted start of the next solve
+      const bool final_now = upd && pass == 0 && s->last_done == 1 && ls.iterations <= verify_above && bnorm > 0.0;
+      int rc2 = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, have_x ? 1.0 : 0.0, 1.0, final_now ? upd : nullptr); if (rc2) return rc2;
+      if (final_now && upd_done) *upd_done = true;
       have_x = true; random_shadow = false;
     } else if (!usable) {
       random_shadow = true; ++bad_passes;
@@ -762,7 +772,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
         if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
         gmpnp_linear_stats_t ls{};
         rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ls); if (rc) return rc;
-        st.direct_solves++;
+        st.direct_solves++; s->x0_predicted = false;
         hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
                            -o.relaxation_parameter, (int)s->ndof);
       } else {
@@ -789,8 +799,16 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // Measured useless: the optimal multiple is ~1e-5 and leaves |r0| = |b| (tools/step_extrapolation.py): the
       // solution moves smoothly in time, but the residual of a new step is not dominated by that motion.
       else if (s->warm_start > 2 && st.iterations == 0 && s->have_step) { wa = 1.0; wb = -1e301; }
+      // coefficients of the NEXT iteration's predicted start (same rule as wa, wb above, one iteration on); the
+      // experiments that decide on host-side dot products of their own keep the separate kernels
+      double na = 0.0, nb = 0.0;
+      if (s->warm_start && s->warm_start <= 2 && q != 0.0) { na = q; if (s->warm_start > 1 && st.iterations + 1 > 1) { na = q + q * q; nb = -q * q * q; } }
+      const NewtonUpdate upd{s->u.p, s->kxp.p, o.relaxation_parameter, na, nb};
+      bool upd_done = false;
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
-                               o.krylov_maximum_iterations, &ls, 500, wa, wb, s->F.p);
+                               o.krylov_maximum_iterations, &ls, 500, wa, wb, nullptr, /*rhs_ready=*/true,
+                               /*x0_ready=*/s->x0_predicted && st.iterations > 0 && wa != 0.0 && !(wb < -1e300),
+                               na != 0.0 ? &upd : nullptr, &upd_done);
       // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
       if (st.iterations < 32) s->hint_by_newton_it[st.iterations] = ls.iterations;
       s->krylov_hint = 0;
@@ -821,9 +839,17 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
         if (*s->h_status) g_err += " [" + status_message(*s->h_status) + "]";
         return rc;
       }
-      // x <- x - omega dx
-      hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
-                         -o.relaxation_parameter, (int)s->ndof);
+      // x <- x - omega dx (done by the solve's last kernel in the normal case)
+      if (upd_done) s->x0_predicted = true;
+      else if (na != 0.0) {
+        hipLaunchKernelGGL(k_update_predict, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, s->kx.p, s->kxp.p,
+                           o.relaxation_parameter, na, nb, (int)s->ndof);
+        s->x0_predicted = true;
+      } else {
+        hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
+                           -o.relaxation_parameter, (int)s->ndof);
+        s->x0_predicted = false;
+      }
     }
     if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[3], s->stream));
     st.iterations++;
@@ -1028,7 +1054,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
   c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.Aci = s->Aci.p;
   c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp[0] = s->kp0.p; c.kp[1] = s->kp1.p; c.kv[0] = s->kv0.p; c.kv[1] = s->kv1.p;
-  c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.yc = s->yc.p;
+  c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.kb = s->kb.p; c.yc = s->yc.p;
   c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
   c.cpart_v[0] = s->cpart_v0.p; c.cpart_v[1] = s->cpart_v1.p; c.cpart_t = s->cpart_t.p;
   c.ticket = s->ticket.p; c.part_a = s->part_a.p; c.part_rr = s->part_a.p + t.ntiles; c.part_b = s->part_b.p;

@@ -147,6 +147,7 @@ struct Ctx {
   double* kt;
   double* ky;
   double* kx;      // work vector (plain SpMV input / M^{-1} output)
+  double* kb;      // right-hand side of the linear solve in flight (k_res_gather leaves b = F in kr and kb)
   double* yc;      // [ncoarse] coarse solve of the half-iteration in flight
   // coarse level: per-tile partial restrictions written by the kernels' epilogues (double-buffered by iteration parity)
   double* cpart_r[2];  // P^T r_k (kernel A)

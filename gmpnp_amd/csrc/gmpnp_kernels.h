@@ -452,6 +452,7 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
       val = s;
     }
     c.F[r] = val;
+    c.kr[r] = val; c.kb[r] = val;   // the next linear solve's right-hand side, where BiCGStab expects it (no copy launch)
   }
   double v[1] = {val * val};
   block_sum<1>(v, lds);
@@ -1557,9 +1558,13 @@ __global__ __launch_bounds__(kVecBlock) void k_restrict(const Ctx c, const doubl
 }
 
 // dst = scale_dst*dst + scale_x * Dinv (x + P Aci P^T x), P^T x taken from the partials k_restrict left in `part`.
+// `upd` (Newton, final application of a solve): in the same pass u -= omega dx and the predicted start of the next
+// linear solve, dst <- a dx + b xp, xp <- dx  (see newton(): a = (1-w) + (1-w)^2, b = -(1-w)^3 from the third iteration on)
+struct NewtonUpdate { double* u; double* xp; double omega, a, b; };
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, const double* __restrict__ x, const double* __restrict__ part,
-                                                                double* __restrict__ dst, double scale_dst, double scale_x) {
+                                                                double* __restrict__ dst, double scale_dst, double scale_x,
+                                                                const NewtonUpdate upd) {
   __shared__ double pcs[kMaxCoarse];
   __shared__ double ycl[kTileAggs * NF];
   __shared__ double xv[kSlicesPerTile][64];
@@ -1601,7 +1606,14 @@ __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, cons
 #pragma unroll
   for (int mI = 0; mI < NF; ++mI) z += d[mI] * xv[sl][Iloc * NF + mI];
   const int r = I * NF + i;
-  dst[r] = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * z;
+  const double dx = (scale_dst == 0.0 ? 0.0 : scale_dst * dst[r]) + scale_x * z;
+  if (upd.u) {
+    upd.u[r] -= upd.omega * dx;
+    dst[r] = upd.a * dx + (upd.b != 0.0 ? upd.b * upd.xp[r] : 0.0);
+    upd.xp[r] = dx;
+  } else {
+    dst[r] = dx;
+  }
 }
 
 // bandwidth probe: stream n doubles (16 B per lane) and keep one checksum per workgroup
@@ -1667,6 +1679,12 @@ __global__ void k_fill_hash(double* __restrict__ v, unsigned seed, int n) {
 }
 
 // warm start of the next Newton correction: x <- a x + b xp, xp <- old x  (x = dx_k, xp = dx_{k-1})
+// u -= omega dx and the predicted start of the next linear solve in one pass (what k_minv_apply does itself at the
+// normal end of a solve; this kernel serves the checked / direct-fallback ends)
+__global__ void k_update_predict(double* __restrict__ u, double* __restrict__ x, double* __restrict__ xp, double omega, double a, double b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double t = x[i]; u[i] -= omega * t; x[i] = a * t + (b != 0.0 ? b * xp[i] : 0.0); xp[i] = t; }
+}
 __global__ void k_warm_start(double* __restrict__ x, double* __restrict__ xp, double a, double b, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double t = x[i]; x[i] = a * t + (b != 0.0 ? b * xp[i] : 0.0); xp[i] = t; }
