@@ -566,7 +566,7 @@ def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):
 
 def _run_pore10(monkeypatch, nsteps=3, **env):
     from gmpnp_amd.pore3d import PoreRun
-    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG"):
+    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG", "GMPNP_HOST_POLL", "GMPNP_GRAPH_ITERS", "GMPNP_PHASE_TIMING"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read by gmpnp_create
@@ -587,6 +587,12 @@ def test_solver_variants_agree(monkeypatch, gpu_lib):
     assert launches_u == 4 and its_u == its and np.array_equal(unfused, ref)
     cold, its_c, _ = _run_pore10(monkeypatch, GMPNP_WARM_START="0", GMPNP_COARSE_LAG="1")
     assert its_c == its and relerr(cold.ravel(), ref.ravel()) < 1e-8
+    # how the host learns about progress (pinned mirror or copy + event), how many iterations it queues per poll and
+    # whether the phases are timed changes no arithmetic at all
+    for env in (dict(GMPNP_HOST_POLL="0"), dict(GMPNP_GRAPH_ITERS="3"), dict(GMPNP_PHASE_TIMING="1"),
+                dict(GMPNP_HOST_POLL="0", GMPNP_FUSED_HALF="0")):
+        other, its_o, _ = _run_pore10(monkeypatch, **env)
+        assert its_o == its and np.array_equal(other, ref), env
 
 
 # field_OHP [V/nm] and eps_rel_OHP "obtained from solving the MPNP code", reference 1D/Stern_CO2ER.py:66-68 — the only
