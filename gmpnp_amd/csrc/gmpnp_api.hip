@@ -117,6 +117,12 @@ struct gmpnp_solver {
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
   // block-banded LU (3D): direct solver / fallback of the Krylov solve; storage is allocated on first use
   DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
+  // asynchronous coarse refresh: the Galerkin product + inverse of THIS iteration's matrix run on a side stream while
+  // BiCGStab uses the inverse built from the previous iteration's matrix; adopted at the next set-up (double buffer)
+  hipStream_t stream2 = nullptr; hipEvent_t ev_mat = nullptr, ev_chain = nullptr;
+  DevBuf<double> Aci2; double* aci_buf[2] = {nullptr, nullptr}; int aci_cur = 0;
+  bool chain_in_flight = false;
+  int coarse_async = 1;       // GMPNP_COARSE_ASYNC=0: rebuild in the main stream every coarse_lag-th iteration (the older scheme)
   bool x0_predicted = false;  // kx holds the predicted start of the next linear solve (left by the previous Newton update)
   bool phase_timing = false;  // GMPNP_PHASE_TIMING=1 fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
   int direct_fallback = 1;      // GMPNP_DIRECT_FALLBACK=0: a failed Krylov solve is an error again
@@ -137,6 +143,9 @@ struct gmpnp_solver {
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_part) (void)hipHostFree(h_part);
     if (h_status) (void)hipHostFree(h_status);
+    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+    if (ev_mat) (void)hipEventDestroy(ev_mat);
+    if (ev_chain) (void)hipEventDestroy(ev_chain);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -272,18 +281,43 @@ int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
 
 // `refresh` = false keeps the previous Dinv and coarse inverse (any nonsingular block scaling and any coarse operator
 // give a valid right preconditioner) and only re-scales the new matrix: the cheap path of a lagged preconditioner.
+template <int NF>
+void launch_coarse_chain(gmpnp_solver* s, const Ctx& c, hipStream_t st) {
+  hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, st, c);
+  hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, st, c);
+  const int n = s->ncoarse;
+  hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, st, c);
+  hipLaunchKernelGGL((k_coarse_invert<NF>), dim3(1), dim3(512), coarse_lds_bytes(n, NF), st, c);
+}
+
+// `allow_async` (Newton): unless `refresh_coarse` demands an inverse of THIS matrix now, the coarse chain of this matrix
+// is started on the side stream and the solve runs with the inverse the previous chain left (any coarse operator gives a
+// valid preconditioner; one iteration of staleness costs < 1 % BiCGStab iterations, the chain is 155 us of a single
+// stream otherwise).  The chain reads vals_s and owns AP / AcPart / Ac: it is awaited (in stream order, the host does
+// not block) before the next k_scale_columns and before any chain in the main stream.
 template <int DIM, int NF>
-int setup_preconditioner(gmpnp_solver* s, int mode, bool refresh = true, bool refresh_coarse = true) {
+int setup_preconditioner(gmpnp_solver* s, int mode, bool refresh = true, bool refresh_coarse = true, bool allow_async = false) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   if (!s->precond_valid || s->precond_mode != mode) refresh = refresh_coarse = true;
   if (refresh) hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 4)), dim3(64), 0, s->stream, s->c);
+  const bool had_chain = s->chain_in_flight;
+  if (had_chain) { HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_chain, 0)); s->chain_in_flight = false; }
   hipLaunchKernelGGL((k_scale_columns<NF>), dim3(grid_for(s->c.n_work * kWave, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
-  if (s->c.use_coarse && refresh && refresh_coarse) {
-    hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
-    hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, s->stream, s->c);
-    const int n = s->ncoarse;
-    hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
-    hipLaunchKernelGGL((k_coarse_invert<NF>), dim3(1), dim3(512), coarse_lds_bytes(n, NF), s->stream, s->c);
+  if (s->c.use_coarse && refresh) {
+    const bool async = allow_async && s->coarse_async && s->stream2 != nullptr;
+    if (async && !refresh_coarse) {
+      if (had_chain) { s->aci_cur ^= 1; s->c.Aci = s->aci_buf[s->aci_cur]; }   // adopt what the previous chain left
+      HIP_TRY(hipEventRecord(s->ev_mat, s->stream));
+      HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_mat, 0));
+      Ctx c2 = s->c; c2.Aci = s->aci_buf[s->aci_cur ^ 1];
+      launch_coarse_chain<NF>(s, c2, s->stream2);
+      HIP_TRY(hipEventRecord(s->ev_chain, s->stream2));
+      s->chain_in_flight = true;
+    } else if (refresh_coarse) {
+      launch_coarse_chain<NF>(s, s->c, s->stream);   // inverse of this matrix, now (a pending side-stream result is dropped)
+      if (async) {   // ... and the double buffer keeps rolling: nothing in flight, the next set-up starts a new chain
+      }
+    }
   }
   HIP_TRY(hipGetLastError());
   s->precond_valid = true; s->precond_mode = mode;
@@ -781,9 +815,13 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     } else {
       // The coarse inverse is reused for up to coarse_lag Newton iterations, unless the state was just set from outside
       // (first solve of a run: the Jacobian changes a lot between iterations) or the last reuse cost iterations.
-      const bool coarse_fresh = s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || s->state_jumped || s->coarse_refresh_due;
+      // Asynchronous scheme (default): every iteration starts the coarse chain of its matrix on the side stream and solves
+      // with the inverse of the previous one; an inverse of THIS matrix is only built in-stream when it has to be.
+      const bool must = s->state_jumped || s->coarse_refresh_due;
+      const bool async_ok = s->coarse_async != 0 && DIM == 3;
+      const bool coarse_fresh = async_ok ? must : (s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || must);
       rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, s->precond_lag <= 1 || (st.iterations % s->precond_lag) == 0,
-                                         coarse_fresh); if (rc) return rc;
+                                         coarse_fresh, async_ok); if (rc) return rc;
       // rhs = b (current residual vector F): copied into kr and kb by krylov_verified
       if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       gmpnp_linear_stats_t ls{};
@@ -1003,6 +1041,10 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
+  HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_mat, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
+  if (const char* pl = std::getenv("GMPNP_COARSE_ASYNC")) s->coarse_async = std::atoi(pl);
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb, &s->kstart, &s->kstep}) HIP_TRY(b->alloc(ndof));
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
@@ -1053,6 +1095,7 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   c.tile_rec = s->tile_rec.p; c.col_stride = t.col_stride; c.tile_cols = s->tile_cols.p; c.tile_colslot = s->tile_colslot.p; c.sell_lcol = s->sell_lcol.p;
   c.Dinv = s->Dinv.p; c.agg = s->agg.p; c.agg_start = s->agg_start.p; c.row_aggs = s->row_aggs.p;
   c.AP = s->AP.p; c.AcPart = s->AcPart.p; c.Ac = s->Ac.p; c.Aci = s->Aci.p;
+  s->aci_buf[0] = s->Aci.p; s->aci_buf[1] = s->Aci2.p; s->aci_cur = 0;
   c.kr = s->kr.p; c.krhat = s->krhat.p; c.kp[0] = s->kp0.p; c.kp[1] = s->kp1.p; c.kv[0] = s->kv0.p; c.kv[1] = s->kv1.p;
   c.ks = s->ks.p; c.kt = s->kt.p; c.ky = s->ky.p; c.kx = s->kx.p; c.kb = s->kb.p; c.yc = s->yc.p;
   c.cpart_r[0] = s->cpart_r0.p; c.cpart_r[1] = s->cpart_r1.p; c.cpart_p[0] = s->cpart_p0.p; c.cpart_p[1] = s->cpart_p1.p;
@@ -1441,7 +1484,7 @@ int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
     case 0: src = s->krhat.p; cap = s->ndof; break;
     case 1: src = s->vals_s.p; cap = (int64_t)s->vals_s.n; break;
     case 2: src = s->Dinv.p; cap = (int64_t)s->Dinv.n; break;
-    case 3: src = s->Aci.p; cap = (int64_t)s->Aci.n; break;
+    case 3: src = s->c.Aci; cap = (int64_t)s->Aci.n; break;
     case 4: src = s->vals.p; cap = (int64_t)s->vals.n; break;
     case 5: src = s->Ac.p; cap = (int64_t)s->Ac.n; break;
     case 6: src = s->kr.p; cap = s->ndof; break;
