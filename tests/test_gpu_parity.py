@@ -566,7 +566,8 @@ def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):
 
 def _run_pore10(monkeypatch, nsteps=3, **env):
     from gmpnp_amd.pore3d import PoreRun
-    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG", "GMPNP_HOST_POLL", "GMPNP_GRAPH_ITERS", "GMPNP_PHASE_TIMING"):
+    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG", "GMPNP_HOST_POLL", "GMPNP_GRAPH_ITERS", "GMPNP_PHASE_TIMING",
+              "GMPNP_COARSE_ASYNC"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read by gmpnp_create
@@ -585,8 +586,14 @@ def test_solver_variants_agree(monkeypatch, gpu_lib):
     assert launches == 2  # L_10_R_5: every workgroup of a launch is resident
     unfused, its_u, launches_u = _run_pore10(monkeypatch, GMPNP_FUSED_HALF="0")
     assert launches_u == 4 and its_u == its and np.array_equal(unfused, ref)
-    cold, its_c, _ = _run_pore10(monkeypatch, GMPNP_WARM_START="0", GMPNP_COARSE_LAG="1")
+    cold, its_c, _ = _run_pore10(monkeypatch, GMPNP_WARM_START="0", GMPNP_COARSE_LAG="1", GMPNP_COARSE_ASYNC="0")
     assert its_c == its and relerr(cold.ravel(), ref.ravel()) < 1e-8
+    # coarse operator rebuilt in the main stream every third iteration instead of on the side stream: another valid
+    # preconditioner, same Newton path; and the side-stream scheme is deterministic (events order the two streams)
+    sync3, its_s, _ = _run_pore10(monkeypatch, GMPNP_COARSE_ASYNC="0")
+    assert its_s == its and relerr(sync3.ravel(), ref.ravel()) < 1e-8
+    again, its_a, _ = _run_pore10(monkeypatch)
+    assert its_a == its and np.array_equal(again, ref)
     # how the host learns about progress (pinned mirror or copy + event), how many iterations it queues per poll and
     # whether the phases are timed changes no arithmetic at all
     for env in (dict(GMPNP_HOST_POLL="0"), dict(GMPNP_GRAPH_ITERS="3"), dict(GMPNP_PHASE_TIMING="1"),
