@@ -119,7 +119,8 @@ struct gmpnp_solver {
   DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
   // asynchronous coarse refresh: the Galerkin product + inverse of THIS iteration's matrix run on a side stream while
   // BiCGStab uses the inverse built from the previous iteration's matrix; adopted at the next set-up (double buffer)
-  hipStream_t stream2 = nullptr; hipEvent_t ev_mat = nullptr, ev_chain = nullptr;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_mat = nullptr, ev_chain = nullptr, ev_jac = nullptr, ev_dots = nullptr;
+  int warm_async = 1;         // GMPNP_WARM_ASYNC=0: test of the predicted start in the main stream, behind the set-up
   DevBuf<double> Aci2; double* aci_buf[2] = {nullptr, nullptr}; int aci_cur = 0;
   bool chain_in_flight = false;
   int coarse_async = 1;       // GMPNP_COARSE_ASYNC=0: rebuild in the main stream every coarse_lag-th iteration (the older scheme)
@@ -146,6 +147,8 @@ struct gmpnp_solver {
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
     if (ev_mat) (void)hipEventDestroy(ev_mat);
     if (ev_chain) (void)hipEventDestroy(ev_chain);
+    if (ev_jac) (void)hipEventDestroy(ev_jac);
+    if (ev_dots) (void)hipEventDestroy(ev_dots);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -509,7 +512,8 @@ int true_residual(gmpnp_solver* s, double* rn) {
 template <int NF>
 int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st,
                     int verify_above = 0, double warm_scale = 0.0, double warm_prev = 0.0, const double* rhs_src = nullptr,
-                    bool rhs_ready = false, bool x0_ready = false, const NewtonUpdate* upd = nullptr, bool* upd_done = nullptr) {
+                    bool rhs_ready = false, bool x0_ready = false, const NewtonUpdate* upd = nullptr, bool* upd_done = nullptr,
+                    bool dots_in_flight = false) {
   const int n = s->ndof;
   const double tol = std::max(rtol * bnorm, atol);
   // kb keeps the right-hand side; `rhs_src` (Newton: F) saves the caller's separate copy into kr
@@ -526,10 +530,15 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     // x0 = theta d with theta minimising ||b - theta J d||: one plain SpMV, three dots, one host round trip
     if (warm_prev < -1e300) HIP_TRY(hipMemcpyAsync(s->kx.p, s->kstep.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     else if (!x0_ready) hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
-    hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
-    hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
-                       s->c.part_f, n, s->n_resblocks);
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (dots_in_flight) {   // w = J x0 and the dot products were started on the side stream right after the Jacobian gather
+      HIP_TRY(hipEventSynchronize(s->ev_dots));
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_dots, 0));   // kt is read by k_line_apply below
+    } else {
+      hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+      hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
+                         s->c.part_f, n, s->n_resblocks);
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     double wb = 0.0, ww = 0.0, bb = 0.0;
     for (int i = 0; i < s->n_resblocks; ++i) { wb += s->h_part[i]; ww += s->h_part[s->n_resblocks + i]; bb += s->h_part[2 * s->n_resblocks + i]; }
     // theta = 1 (the predicted correction as it is).  The minimal-residual multiple theta = (w,b)/(w,w) makes |r0| smaller
@@ -817,6 +826,29 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // (first solve of a run: the Jacobian changes a lot between iterations) or the last reuse cost iterations.
       // Asynchronous scheme (default): every iteration starts the coarse chain of its matrix on the side stream and solves
       // with the inverse of the previous one; an inverse of THIS matrix is only built in-stream when it has to be.
+      // x0 = (1-w) dx_k + (1-w)^2 (dx_k - (1-w) dx_{k-1}): first-order prediction plus the second-order term observed
+      // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (GMPNP_WARM_START=1: first order only)
+      const double q = 1.0 - o.relaxation_parameter;
+      double wa = 0.0, wb = 0.0;
+      if (s->warm_start && st.iterations > 0 && q != 0.0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
+      // first linear solve of a time step: the previous step's total update as search direction (GMPNP_WARM_START=3).
+      // Measured useless: the optimal multiple is ~1e-5 and leaves |r0| = |b| (tools/step_extrapolation.py): the
+      // solution moves smoothly in time, but the residual of a new step is not dominated by that motion.
+      else if (s->warm_start > 2 && st.iterations == 0 && s->have_step) { wa = 1.0; wb = -1e301; }
+      const bool x0_ready = s->x0_predicted && st.iterations > 0 && wa != 0.0 && !(wb < -1e300);
+      // The test of the predicted start (w = J x0 and three dot products, then a host decision) needs the new Jacobian
+      // only: it runs on the side stream while the main stream builds the preconditioner, and the host waits for ITS
+      // event, so neither the two kernels nor the round trip sit on the critical path.
+      bool dots_in_flight = false;
+      if (x0_ready && s->stream2 && s->warm_async) {
+        HIP_TRY(hipEventRecord(s->ev_jac, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_jac, 0));
+        hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream2, s->c, (const double*)s->kx.p, s->kt.p);
+        hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream2, (const double*)s->kt.p, (const double*)s->kb.p,
+                           s->c.part_f, (int)s->ndof, s->n_resblocks);
+        HIP_TRY(hipEventRecord(s->ev_dots, s->stream2));
+        dots_in_flight = true;
+      }
       const bool must = s->state_jumped || s->coarse_refresh_due;
       const bool async_ok = s->coarse_async != 0 && DIM == 3;
       const bool coarse_fresh = async_ok ? must : (s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || must);
@@ -827,16 +859,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       gmpnp_linear_stats_t ls{};
       // inside Newton only long solves are checked: a short one does not drift, and Newton's own residual test sees
       // whatever is left
-      // x0 = (1-w) dx_k + (1-w)^2 (dx_k - (1-w) dx_{k-1}): first-order prediction plus the second-order term observed
-      // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (GMPNP_WARM_START=1: first order only)
       s->krylov_hint = st.iterations < 32 ? s->hint_by_newton_it[st.iterations] : 0;
-      const double q = 1.0 - o.relaxation_parameter;
-      double wa = 0.0, wb = 0.0;
-      if (s->warm_start && st.iterations > 0 && q != 0.0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
-      // first linear solve of a time step: the previous step's total update as search direction (GMPNP_WARM_START=3).
-      // Measured useless: the optimal multiple is ~1e-5 and leaves |r0| = |b| (tools/step_extrapolation.py): the
-      // solution moves smoothly in time, but the residual of a new step is not dominated by that motion.
-      else if (s->warm_start > 2 && st.iterations == 0 && s->have_step) { wa = 1.0; wb = -1e301; }
       // coefficients of the NEXT iteration's predicted start (same rule as wa, wb above, one iteration on); the
       // experiments that decide on host-side dot products of their own keep the separate kernels
       double na = 0.0, nb = 0.0;
@@ -845,8 +868,8 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       bool upd_done = false;
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
                                o.krylov_maximum_iterations, &ls, 500, wa, wb, nullptr, /*rhs_ready=*/true,
-                               /*x0_ready=*/s->x0_predicted && st.iterations > 0 && wa != 0.0 && !(wb < -1e300),
-                               na != 0.0 ? &upd : nullptr, &upd_done);
+                               x0_ready, na != 0.0 ? &upd : nullptr, &upd_done, dots_in_flight);
+      if (dots_in_flight) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_dots, 0));  // whatever path the solve took: kt and vals are free again
       // feedback: a reused coarse inverse that doubles the iteration count of the last fresh solve is dropped
       if (st.iterations < 32) s->hint_by_newton_it[st.iterations] = ls.iterations;
       s->krylov_hint = 0;
@@ -1044,7 +1067,9 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&s->ev_mat, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&s->ev_jac, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_dots, hipEventDisableTiming));
   if (const char* pl = std::getenv("GMPNP_COARSE_ASYNC")) s->coarse_async = std::atoi(pl);
+  if (const char* pl = std::getenv("GMPNP_WARM_ASYNC")) s->warm_async = std::atoi(pl);
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb, &s->kstart, &s->kstep}) HIP_TRY(b->alloc(ndof));
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})

@@ -567,7 +567,7 @@ def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):
 def _run_pore10(monkeypatch, nsteps=3, **env):
     from gmpnp_amd.pore3d import PoreRun
     for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG", "GMPNP_HOST_POLL", "GMPNP_GRAPH_ITERS", "GMPNP_PHASE_TIMING",
-              "GMPNP_COARSE_ASYNC"):
+              "GMPNP_COARSE_ASYNC", "GMPNP_WARM_ASYNC"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read by gmpnp_create
@@ -596,7 +596,7 @@ def test_solver_variants_agree(monkeypatch, gpu_lib):
     assert its_a == its and np.array_equal(again, ref)
     # how the host learns about progress (pinned mirror or copy + event), how many iterations it queues per poll and
     # whether the phases are timed changes no arithmetic at all
-    for env in (dict(GMPNP_HOST_POLL="0"), dict(GMPNP_GRAPH_ITERS="3"), dict(GMPNP_PHASE_TIMING="1"),
+    for env in (dict(GMPNP_HOST_POLL="0"), dict(GMPNP_GRAPH_ITERS="3"), dict(GMPNP_PHASE_TIMING="1"), dict(GMPNP_WARM_ASYNC="0"),
                 dict(GMPNP_HOST_POLL="0", GMPNP_FUSED_HALF="0")):
         other, its_o, _ = _run_pore10(monkeypatch, **env)
         assert its_o == its and np.array_equal(other, ref), env
