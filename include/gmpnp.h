@@ -13,8 +13,11 @@
  * Conventions: plain C types; caller-allocated contiguous fp64 / int32 / int64 host buffers; all
  * vertex-indexed data in mesh-FILE vertex order, dof = vertex * n_fields + field (fields = species in
  * mixed-space order, potential last); the library owns all device memory behind the opaque handle;
- * every function returns 0 or a negative gmpnp_status and never throws; one host thread and one HIP
- * stream per handle; calls block until the result is on the host.
+ * every function returns 0 or a negative gmpnp_status and never throws; one host thread per handle; a handle
+ * owns its HIP streams (the main one and a side stream for work that is off the critical path of a Newton
+ * iteration, ordered by events) and a few pinned host cache lines the kernels report progress into; calls
+ * block until their result is on the host (gmpnp_assign_previous is stream-ordered: it returns at once, and
+ * whatever reads u_n next is queued behind the copy).
  */
 #ifndef GMPNP_H
 #define GMPNP_H
@@ -142,7 +145,9 @@ typedef struct {
   int32_t device_id;      /* HIP device ordinal */
   int32_t n_aggregates;   /* coarse-space slabs; 0 = default (8; at most 16 and what the LDS-resident coarse inverse allows) */
   int32_t use_graph;      /* reserved (the Krylov launches carry the iteration index as an argument: eager only) */
-  int32_t krylov_batch;   /* iterations launched between convergence read-backs; 0 = default */
+  int32_t krylov_batch;   /* iterations of the first burst of a BiCGStab solve; 0 = default (sized from the
+                             previous solves; afterwards the host keeps one iteration queued ahead of the progress
+                             the kernels report into pinned memory) */
   int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */
 } gmpnp_options_t;
 
