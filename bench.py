@@ -84,7 +84,14 @@ def main():
     # rehearsal on a one-GPU box: GMPNP_BENCH_BACKEND=gloo lets several ranks share the card (ranks map onto the visible
     # devices modulo their count); the driver's runs use RCCL ("nccl") with one rank per GPU
     backend = os.environ.get("GMPNP_BENCH_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
+        # several PROCESSES on one card (rehearsal only; the contract is one rank per GPU): a second hardware queue per
+        # process makes the processes time-slice 3x slower (measured 290 vs 857 its/s for two ranks), so the handle
+        # is created without its side stream
+        os.environ.setdefault("GMPNP_COARSE_ASYNC", "0")
+        os.environ.setdefault("GMPNP_WARM_ASYNC", "0")
+    local = local % ndev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1065,11 +1065,13 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
   HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_mat, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&s->ev_jac, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_dots, hipEventDisableTiming));
   if (const char* pl = std::getenv("GMPNP_COARSE_ASYNC")) s->coarse_async = std::atoi(pl);
   if (const char* pl = std::getenv("GMPNP_WARM_ASYNC")) s->warm_async = std::atoi(pl);
+  if (s->coarse_async || s->warm_async) {   // the side stream exists only when something uses it
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_mat, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_jac, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_dots, hipEventDisableTiming));
+  }
   for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb, &s->kstart, &s->kstep}) HIP_TRY(b->alloc(ndof));
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
