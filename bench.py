@@ -85,12 +85,10 @@ def main():
     # devices modulo their count); the driver's runs use RCCL ("nccl") with one rank per GPU
     backend = os.environ.get("GMPNP_BENCH_BACKEND", "nccl")
     ndev = max(1, torch.cuda.device_count())
-    if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
-        # several PROCESSES on one card (rehearsal only; the contract is one rank per GPU): a second hardware queue per
-        # process makes the processes time-slice 3x slower (measured 290 vs 857 its/s for two ranks), so the handle
-        # is created without its side stream
-        os.environ.setdefault("GMPNP_COARSE_ASYNC", "0")
-        os.environ.setdefault("GMPNP_WARM_ASYNC", "0")
+    # several PROCESSES on one card (rehearsal only; the contract is one rank per GPU): a second hardware queue per
+    # process makes the processes time-slice 3x slower (measured 290 vs 857 its/s for two ranks) and an in-launch
+    # hand-over must not wait on workgroups another process keeps off the machine: gmpnp_options_t.shared_device
+    shared = int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev
     local = local % ndev
     if world > 1:
         import torch.distributed as dist
@@ -114,7 +112,7 @@ def main():
 
     _, Lnm, _, Rnm = a.mesh.split("_")
     run = PoreRun(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine,
-                  device_kwargs={"device_id": local, "use_graph": False,
+                  device_kwargs={"device_id": local, "shared_device": int(shared),
                                  "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "32"))})
     nv = run.mesh.num_vertices
 

@@ -61,8 +61,12 @@ class CLinearStats(ctypes.Structure):
 
 
 class COptions(ctypes.Structure):
-    _fields_ = [("device_id", c_int32), ("n_aggregates", c_int32), ("use_graph", c_int32),
-                ("krylov_batch", c_int32), ("profile_every", c_int32)]
+    """gmpnp_options_t: zero = default for every field (include/gmpnp.h)."""
+    _fields_ = [("device_id", c_int32), ("n_aggregates", c_int32), ("shared_device", c_int32),
+                ("krylov_batch", c_int32), ("profile_every", c_int32), ("launch_form", c_int32),
+                ("warm_start", c_int32), ("coarse_refresh", c_int32), ("progress_by_copy", c_int32),
+                ("burst_iterations", c_int32), ("phase_timing", c_int32), ("no_direct_fallback", c_int32),
+                ("warm_in_stream", c_int32), ("reserved_", c_int32 * 3), ("band_lu_max_gb", c_double)]
 
 
 class GmpnpError(RuntimeError):
@@ -201,8 +205,11 @@ def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptio
 class DeviceSolver:
     """Device-resident GMPNP problem (one handle = one GPU, one HIP stream)."""
 
-    def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, use_graph: bool = True,
-                 krylov_batch: int = 0, profile_every: int = 0, perm: np.ndarray = None, lib=None):
+    def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, krylov_batch: int = 0,
+                 profile_every: int = 0, perm: np.ndarray = None, lib=None, **options):
+        """``options``: further fields of ``gmpnp_options_t`` by name (shared_device, launch_form, warm_start,
+        coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream,
+        band_lu_max_gb); all default to 0."""
         self.lib = lib or load_library()
         self.problem = problem
         self.nf = problem.nf
@@ -222,9 +229,12 @@ class DeviceSolver:
         m.n_exit_facets, m.exit_facets = len(self._exit), _iptr(self._exit)
         m.n_point_vertices, m.point_vertices = len(self._pts), _iptr(self._pts)
         cm, cq = to_cmodel(problem.model), to_cquadrature(problem.quad)
-        if os.environ.get("GMPNP_USE_GRAPH", "1") == "0":
-            use_graph = False
-        opts = COptions(device_id, n_aggregates, 0 if use_graph else 2, krylov_batch, profile_every)
+        opts = COptions(device_id=device_id, n_aggregates=n_aggregates, krylov_batch=krylov_batch, profile_every=profile_every)
+        known = {f[0] for f in COptions._fields_} - {"reserved_"}
+        for k, v in options.items():
+            if k not in known:
+                raise TypeError("unknown gmpnp_options_t field %r" % k)
+            setattr(opts, k, v)
         h = c_void_p()
         self._h = None
         self._check(self.lib.gmpnp_create(byref(m), byref(cm), byref(cq), byref(opts), byref(h)))

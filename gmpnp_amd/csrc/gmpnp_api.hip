@@ -71,7 +71,7 @@ struct gmpnp_solver {
   // device storage
   DevBuf<gmpnp_model_t> d_model; DevBuf<gmpnp_quadrature_t> d_quad;
   DevBuf<double> coords, u, un, F, bcval, bndF, rob_val, EF, EJ, vals, vals_s, Dinv, AP, AcPart, Ac, Aci;
-  DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, kxp, kb, kstart, kstep, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
+  DevBuf<double> kr, krhat, kp0, kp1, kv0, kv1, ks, kt, ky, kx, kxp, kb, yc, cpart_r0, cpart_r1, cpart_p0, cpart_p1, cpart_v0, cpart_v1, cpart_t,
       part_a, part_b, part_f;
   DevBuf<int32_t> cells, robF_ptr, rob_col, rob_row, n2e_ptr, n2e, rowptr, cols, cptr, contrib, slice_colbase,
       slice_node0, slice_nn, node_slice, sell_cols, sell_blk, wl_slice, wl_kpos, tile_slice0, tile_agg, tile_slot,
@@ -85,30 +85,28 @@ struct gmpnp_solver {
   // pinned read-back areas
   KrylovScalars* h_scal = nullptr; double* h_part = nullptr; int32_t* h_status = nullptr;
   HostPoll* h_poll = nullptr;   // progress mirror the B kernels write (fine-grained pinned memory)
-  int host_poll = 1;            // GMPNP_HOST_POLL=0: poll with a device-to-host copy + event per burst instead
-  // Krylov graph (one per preconditioner mode)
-  int graph_iters = 1;  // iterations per polling burst (the name dates from the hipGraph experiment: replay = eager, dropped);
-                        // with copy + event polling: 1 -> 453, 2 -> 463, 4 -> 456, 8 -> 436 Newton its/s; with the pinned
-                        // progress mirror a poll costs nothing on the device: 1 -> 496, 2 -> 492
+  int host_poll = 1;            // opts.progress_by_copy: poll with a device-to-host copy + event per burst instead
+  int burst_iters = 1;  // iterations per polling burst (opts.burst_iterations); with copy + event polling: 1 -> 453, 2 -> 463,
+                        // 4 -> 456, 8 -> 436 Newton its/s; with the pinned progress mirror a poll costs nothing on the
+                        // device: 1 -> 496, 2 -> 492
   int krylov_hint = 0;  // expected iterations of the next solve (the same Newton iteration of the previous time step), 0 = none
   int hint_by_newton_it[32] = {0};
   int last_krylov_iters[2] = {0, 0};
   bool jacobian_valid = false, precond_valid = false;
   int precond_mode = -1;
-  int precond_lag = 1;  // rebuild Dinv / coarse inverse every precond_lag-th Newton iteration of a solve
-  const double* shadow_src = nullptr; double shadow_rho0 = 0.0;  // experiment: shadow vector of the next krylov() call
+  const double* shadow_src = nullptr; double shadow_rho0 = 0.0;  // shadow vector of the next krylov() pass (after a breakdown: krand)
   int last_done = 0;            // exit code of the last device Krylov loop (1 converged, 2 iteration cap, 3 breakdown / divergence)
   DevBuf<double> krand;         // pseudo-random shadow vector for a pass that follows a breakdown
-  bool have_step = false;       // kstep holds the total update of the previous Newton solve (same time series)
   bool state_jumped = true;     // u was set from outside since the last Newton solve: the Jacobian moves a lot, no coarse reuse
   bool coarse_refresh_due = false;  // a solve with a reused coarse inverse took clearly longer than the last fresh one
   int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
   DevBuf<uint32_t> ticket;
   DevBuf<double> supg_rho;  // [nv][ns] internal order
   DevBuf<int32_t> perm_dev;  // file vertex of each internal node (device-pointer entry points)
-  bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); GMPNP_FUSED_HALF=1
+  bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); opts.launch_form
+  int resident_slots = 0;   // workgroups of k_half_a/b the device holds at once (occupancy query at create)
   unsigned fused_seq = 0;   // fused launches so far in the current solve
-  int warm_start = 2;  // start Newton iteration k+1's linear solve from (1 - omega) dx_k (GMPNP_WARM_START=0 disables)
+  int warm_start = 2;  // start Newton iteration k+1's linear solve from (1 - omega) dx_k (+ second-order term); opts.warm_start
   int coarse_lag = 3;   // rebuild the coarse inverse alone every coarse_lag-th Newton iteration of a solve (measured best: 1 -> 3 costs 0.7 % more Krylov iterations and saves 155 us per skipped rebuild)
   // SpMV event sampling (eager mode)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
@@ -120,14 +118,14 @@ struct gmpnp_solver {
   // asynchronous coarse refresh: the Galerkin product + inverse of THIS iteration's matrix run on a side stream while
   // BiCGStab uses the inverse built from the previous iteration's matrix; adopted at the next set-up (double buffer)
   hipStream_t stream2 = nullptr; hipEvent_t ev_mat = nullptr, ev_chain = nullptr, ev_jac = nullptr, ev_dots = nullptr;
-  int warm_async = 1;         // GMPNP_WARM_ASYNC=0: test of the predicted start in the main stream, behind the set-up
+  int warm_async = 1;         // opts.warm_in_stream: test of the predicted start in the main stream, behind the set-up
   DevBuf<double> Aci2; double* aci_buf[2] = {nullptr, nullptr}; int aci_cur = 0;
   bool chain_in_flight = false;
-  int coarse_async = 1;       // GMPNP_COARSE_ASYNC=0: rebuild in the main stream every coarse_lag-th iteration (the older scheme)
+  int coarse_async = 1;       // opts.coarse_refresh = N: rebuild in the main stream every Nth iteration (the older scheme)
   bool x0_predicted = false;  // kx holds the predicted start of the next linear solve (left by the previous Newton update)
-  bool phase_timing = false;  // GMPNP_PHASE_TIMING=1 fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
-  int direct_fallback = 1;      // GMPNP_DIRECT_FALLBACK=0: a failed Krylov solve is an error again
-  double lu_max_gb = 48.0;      // GMPNP_BAND_LU_MAX_GB: largest band storage the fallback may allocate
+  bool phase_timing = false;  // opts.phase_timing fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
+  int direct_fallback = 1;      // opts.no_direct_fallback: a failed Krylov solve is an error again
+  double lu_max_gb = 48.0;      // opts.band_lu_max_gb: largest band storage the fallback may allocate
   int direct_solves = 0;        // band LU solves since create (factorisations)
   int direct_sticky = 0;        // Newton solves that still go straight to the band LU after a Krylov failure
   int direct_backoff = 0;       // length of the last such stretch (doubles with every new failure, resets on a converged Krylov solve)
@@ -404,7 +402,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   volatile HostPoll* hp = s->h_poll;
   hp->done = 0; hp->iters = 0; hp->rr = 0.0;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  const int B = s->graph_iters;
+  const int B = s->burst_iters;
   // Bursts of B iterations.  The first burst is 3/4 of what the previous solve with this preconditioner
   // needed; after that the host polls the device flag one burst BEHIND the launches (copy + event, launch the
   // next burst, then wait for the event), so the read-back latency hides behind queued work.  Kernels of a
@@ -415,8 +413,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   // With the pinned progress mirror the host keeps up one iteration at a time, so the first burst is insurance against
   // a slow host rather than a way to save polls: half the expected count (measured on the bench, sixteenths of the
   // hint: 0..8 -> 529-533 its/s, 12 -> 525, 14 -> 522, 16 -> 516; more surplus early-exit launches the longer it is).
-  static const int hint16 = std::getenv("GMPNP_HINT_FRAC16") ? std::atoi(std::getenv("GMPNP_HINT_FRAC16")) : 8;
-  const int expect = s->krylov_hint > 0 ? (hint16 * s->krylov_hint) / 16 : s->last_krylov_iters[use_coarse] / 2;
+  const int expect = s->krylov_hint > 0 ? s->krylov_hint / 2 : s->last_krylov_iters[use_coarse] / 2;
   int first = s->opts.krylov_batch > 0 ? s->opts.krylov_batch : std::max(B, expect);
   if (restart) first = B;  // a restart pass only has to remove the drift
   first = ((first + B - 1) / B) * B;
@@ -518,6 +515,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
                     bool rhs_ready = false, bool x0_ready = false, const NewtonUpdate* upd = nullptr, bool* upd_done = nullptr,
                     bool dots_in_flight = false) {
   const int n = s->ndof;
+  if (!std::isfinite(bnorm)) return fail(GMPNP_ERR_LINEAR, "right-hand side of the linear system is not finite");
   const double tol = std::max(rtol * bnorm, atol);
   // kb keeps the right-hand side; `rhs_src` (Newton: F) saves the caller's separate copy into kr
   // `rhs_ready`: k_res_gather already left b in kr and kb (Newton)
@@ -529,13 +527,12 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
   double rhs_norm = bnorm;
   bool warm = false;
   if (warm_scale != 0.0 && bnorm > 0.0) {
-    // direction d = warm_scale * kx + warm_prev * kxp (warm_prev < -1e300: d = kstep, the previous time step's update);
-    // x0 = theta d with theta minimising ||b - theta J d||: one plain SpMV, three dots, one host round trip
-    if (warm_prev < -1e300) HIP_TRY(hipMemcpyAsync(s->kx.p, s->kstep.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
-    else if (!x0_ready) hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
+    // x0 = warm_scale * kx + warm_prev * kxp (left in kx by the previous Newton update when `x0_ready`); accepted when
+    // it removes at least half of the residual: one plain SpMV, three dots, one host round trip
+    if (!x0_ready) hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, warm_scale, warm_prev, n);
     if (dots_in_flight) {   // w = J x0 and the dot products were started on the side stream right after the Jacobian gather
       HIP_TRY(hipEventSynchronize(s->ev_dots));
-      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_dots, 0));   // kt is read by k_line_apply below
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_dots, 0));   // kt is read by k_start_residual below
     } else {
       hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
       hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
@@ -544,20 +541,13 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     }
     double wb = 0.0, ww = 0.0, bb = 0.0;
     for (int i = 0; i < s->n_resblocks; ++i) { wb += s->h_part[i]; ww += s->h_part[s->n_resblocks + i]; bb += s->h_part[2 * s->n_resblocks + i]; }
-    // theta = 1 (the predicted correction as it is).  The minimal-residual multiple theta = (w,b)/(w,w) makes |r0| smaller
-    // every time (iteration 1 of a step: 1e-3 |b| at theta = -4.5 instead of 1.2 |b|) and BiCGStab slower all the same
-    // (18.8k instead of 17.3k iterations over the bench): GMPNP_LINE_SEARCH=1 keeps the experiment reachable.
-    static const int ls_mode = std::getenv("GMPNP_LINE_SEARCH") ? std::atoi(std::getenv("GMPNP_LINE_SEARCH")) : 0;
-    double theta = 1.0;
-    if (ls_mode == 1 || warm_prev < -1e300) theta = ww > 0.0 ? wb / ww : 0.0;
-    const double rn2 = bb - 2.0 * theta * wb + theta * theta * ww;  // ||b - theta w||^2
-    if (std::getenv("GMPNP_DEBUG_WARM")) fprintf(stderr, "warm: step-dir %d theta %.6f  |r0|/|b| %.3e  (theta=1: %.3e)\n", warm_prev < -1e300 ? 1 : 0, theta, std::sqrt(std::max(rn2, 0.0) / bb), std::sqrt(std::max(bb - 2 * wb + ww, 0.0) / bb));
-    if (theta == theta && rn2 == rn2 && rn2 >= 0.0 && rn2 < 0.25 * bb) {
-      hipLaunchKernelGGL(k_line_apply, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kr.p, (const double*)s->kb.p,
-                         (const double*)s->kt.p, theta, n);
+    // The predicted correction is taken as it is.  (Scaling it by the minimal-residual multiple (w,b)/(w,w) makes |r0|
+    // smaller every time and BiCGStab slower all the same: 18.8k instead of 17.3k iterations over the bench, round 1.)
+    const double rn2 = bb - 2.0 * wb + ww;  // ||b - w||^2
+    if (rn2 == rn2 && rn2 >= 0.0 && rn2 < 0.25 * bb) {
+      hipLaunchKernelGGL(k_start_residual, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kr.p, (const double*)s->kb.p,
+                         (const double*)s->kt.p, n);
       warm = true; rhs_norm = std::sqrt(rn2);
-      static const bool shadow_b = std::getenv("GMPNP_SHADOW_B") && std::atoi(std::getenv("GMPNP_SHADOW_B"));
-      if (shadow_b) { s->shadow_src = s->kb.p; s->shadow_rho0 = bb - theta * wb; }  // (b, r0)
     }  // else: kr still holds b, cold start
   }
   // Restarted BiCGStab.  A pass runs at most `restart_every` iterations; then (and after a breakdown) the true residual
@@ -566,7 +556,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
   // thinnest pores (L_50_R_1: ||r|| reached 1e53 inside 10,000 unrestarted iterations, the reference's direct solver
   // sails through).  A pass that ends in a breakdown or in a residual 1e5 times its start (device test) is thrown away
   // and repeated with a pseudo-random shadow vector.  Short solves (the normal case) take exactly one pass and no check.
-  static const int restart_every = std::getenv("GMPNP_RESTART_EVERY") ? std::max(20, std::atoi(std::getenv("GMPNP_RESTART_EVERY"))) : 1000;
+  constexpr int restart_every = 1000;
   bool have_x = warm;      // kx holds a partial solution
   bool random_shadow = false;
   int bad_passes = 0;
@@ -601,12 +591,6 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       have_x = true; random_shadow = false;
     } else if (!usable) {
       random_shadow = true; ++bad_passes;
-      if (std::getenv("GMPNP_DEBUG_WARM")) {
-        HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-        KrylovScalars dbg; HIP_TRY(hipMemcpy(&dbg, s->scal.p, sizeof dbg, hipMemcpyDeviceToHost));
-        fprintf(stderr, "bad pass %d: its %d status %d rr %.3e rr0 %.3e rho %.3e %.3e alpha %.3e omega %.3e beta %.3e\n", pass, ls.iterations, *s->h_status,
-                dbg.rr, dbg.rr0, dbg.rho[0], dbg.rho[1], dbg.alpha, dbg.omega, dbg.beta);
-      }
       HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
       if (!have_x) HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));  // kr was the work vector
     }
@@ -620,8 +604,11 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     total.residual_norm = rn;
     // Converged by the recurrence and within 1000x of the target by the true residual: accepted.  (A 1e-10 solve of a
     // small right-hand side ends at the attainable accuracy of b - J dx in fp64, 3-30x the target late in a run.)
-    if (s->last_done == 1 && (rn <= 1e3 * tol || !(rn == rn))) break;
-    if (total.iterations >= maxit || bad_passes > 8 || !(rn == rn)) {
+    // A non-finite true residual is a failed solve whatever the recurrence reported: the caller's direct fallback takes
+    // over (3D) and nothing of this x reaches u.
+    const bool finite = std::isfinite(rn);
+    if (s->last_done == 1 && finite && rn <= 1e3 * tol) break;
+    if (total.iterations >= maxit || bad_passes > 8 || !finite) {
       if (st) { total.converged = 0; *st = total; }
       char buf[200];
       snprintf(buf, sizeof buf, "BiCGStab stopped without convergence after %d iterations in %d passes (%d breakdowns), ||b - J x|| = %.3e, ||b|| = %.3e",
@@ -780,8 +767,6 @@ template <int DIM, int NF>
 int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_t& st) {
   const double t0 = now_ms();
   HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
-  if (s->state_jumped) s->have_step = false;
-  if (s->warm_start > 2) HIP_TRY(hipMemcpyAsync(s->kstart.p, s->u.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
   double r = 0.0; int flags = 0;
   double ta = now_ms();
   // Every residual evaluation also leaves the element Jacobian records (k_element<.., true>, 43 us instead of 27): the
@@ -834,11 +819,9 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       const double q = 1.0 - o.relaxation_parameter;
       double wa = 0.0, wb = 0.0;
       if (s->warm_start && st.iterations > 0 && q != 0.0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
-      // first linear solve of a time step: the previous step's total update as search direction (GMPNP_WARM_START=3).
-      // Measured useless: the optimal multiple is ~1e-5 and leaves |r0| = |b| (tools/step_extrapolation.py): the
-      // solution moves smoothly in time, but the residual of a new step is not dominated by that motion.
-      else if (s->warm_start > 2 && st.iterations == 0 && s->have_step) { wa = 1.0; wb = -1e301; }
-      const bool x0_ready = s->x0_predicted && st.iterations > 0 && wa != 0.0 && !(wb < -1e300);
+      // (The previous time step's total update is useless as a start of a step's FIRST solve: optimal multiple ~1e-5,
+      // measured in round 1.)
+      const bool x0_ready = s->x0_predicted && st.iterations > 0 && wa != 0.0;
       // The test of the predicted start (w = J x0 and three dot products, then a host decision) needs the new Jacobian
       // only: it runs on the side stream while the main stream builds the preconditioner, and the host waits for ITS
       // event, so neither the two kernels nor the round trip sit on the critical path.
@@ -855,8 +838,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       const bool must = s->state_jumped || s->coarse_refresh_due;
       const bool async_ok = s->coarse_async != 0 && DIM == 3;
       const bool coarse_fresh = async_ok ? must : (s->coarse_lag <= 1 || (st.iterations % s->coarse_lag) == 0 || must);
-      rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, s->precond_lag <= 1 || (st.iterations % s->precond_lag) == 0,
-                                         coarse_fresh, async_ok); if (rc) return rc;
+      rc = setup_preconditioner<DIM, NF>(s, o.linear_solver, true, coarse_fresh, async_ok); if (rc) return rc;
       // rhs = b (current residual vector F): copied into kr and kb by krylov_verified
       if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
       gmpnp_linear_stats_t ls{};
@@ -866,7 +848,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // coefficients of the NEXT iteration's predicted start (same rule as wa, wb above, one iteration on); the
       // experiments that decide on host-side dot products of their own keep the separate kernels
       double na = 0.0, nb = 0.0;
-      if (s->warm_start && s->warm_start <= 2 && q != 0.0) { na = q; if (s->warm_start > 1 && st.iterations + 1 > 1) { na = q + q * q; nb = -q * q * q; } }
+      if (s->warm_start && q != 0.0) { na = q; if (s->warm_start > 1 && st.iterations + 1 > 1) { na = q + q * q; nb = -q * q * q; } }
       const NewtonUpdate upd{s->u.p, s->kxp.p, o.relaxation_parameter, na, nb};
       bool upd_done = false;
       rc = krylov_verified<NF>(s, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance,
@@ -939,11 +921,6 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
   }
   s->state_jumped = false;
   if (s->direct_sticky > 0 && o.linear_solver != GMPNP_LINEAR_BAND_LU) s->direct_sticky--;
-  if (st.iterations > 0 && DIM == 3 && s->warm_start > 2) {  // total update of this solve, in the sign convention of dx (u_new = u - omega dx)
-    hipLaunchKernelGGL(k_diff, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->kstep.p, (const double*)s->kstart.p,
-                       (const double*)s->u.p, (int)s->ndof);
-    s->have_step = true;
-  }
   st.converged = done ? 1 : 0;
   st.ms_total = now_ms() - t0;
   if (!done) return fail(GMPNP_ERR_NOT_CONVERGED, "Newton solver did not converge because maximum number of iterations reached");
@@ -1068,14 +1045,25 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
   HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
-  if (const char* pl = std::getenv("GMPNP_COARSE_ASYNC")) s->coarse_async = std::atoi(pl);
-  if (const char* pl = std::getenv("GMPNP_WARM_ASYNC")) s->warm_async = std::atoi(pl);
+  const gmpnp_options_t& po = s->opts;
+  if (po.launch_form != 0 && po.launch_form != 2 && po.launch_form != 4) return fail(GMPNP_ERR_INVALID, "launch_form must be 0, 2 or 4");
+  if (po.coarse_refresh < 0 || po.burst_iterations < 0 || po.warm_start < -1 || po.warm_start > 1 || !(po.band_lu_max_gb >= 0.0))
+    return fail(GMPNP_ERR_INVALID, "option out of range");
+  s->coarse_async = (po.coarse_refresh == 0 && !po.shared_device) ? 1 : 0;
+  s->coarse_lag = po.coarse_refresh > 0 ? po.coarse_refresh : 3;
+  s->warm_async = (po.warm_in_stream || po.shared_device) ? 0 : 1;
+  s->warm_start = po.warm_start == 0 ? 2 : (po.warm_start == 1 ? 1 : 0);
+  s->host_poll = po.progress_by_copy ? 0 : 1;
+  s->burst_iters = std::max(1, po.burst_iterations);
+  s->phase_timing = po.phase_timing != 0;
+  s->direct_fallback = po.no_direct_fallback ? 0 : 1;
+  if (po.band_lu_max_gb > 0.0) s->lu_max_gb = po.band_lu_max_gb;
   if (s->coarse_async || s->warm_async) {   // the side stream exists only when something uses it
     HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_mat, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_jac, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_dots, hipEventDisableTiming));
   }
-  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb, &s->kstart, &s->kstep}) HIP_TRY(b->alloc(ndof));
+  for (DevBuf<double>* b : {&s->kr, &s->krhat, &s->kp0, &s->kp1, &s->kv0, &s->kv1, &s->ks, &s->kt, &s->ky, &s->kx, &s->kxp, &s->kb}) HIP_TRY(b->alloc(ndof));
   HIP_TRY(s->yc.alloc((size_t)kMaxCoarse * 32));  // [nagg <= 16][ncoarse] column-block products (+ development stamps)
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
@@ -1090,22 +1078,28 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   HIP_TRY(hipHostMalloc((void**)&s->h_poll, 64, hipHostMallocCoherent | hipHostMallocMapped));
   std::memset(s->h_poll, 0, 64);
   { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, s->h_poll, 0)); s->c.poll = (HostPoll*)dp; }
-  if (const char* pl = std::getenv("GMPNP_HOST_POLL")) s->host_poll = std::atoi(pl);
   for (auto& e : s->ev_poll) HIP_TRY(hipEventCreate(&e));
-  if (const char* gi = std::getenv("GMPNP_GRAPH_ITERS")) s->graph_iters = std::max(1, std::atoi(gi));
-  if (const char* pl = std::getenv("GMPNP_PRECOND_LAG")) s->precond_lag = std::max(1, std::atoi(pl));
-  if (const char* pl = std::getenv("GMPNP_COARSE_LAG")) s->coarse_lag = std::max(1, std::atoi(pl));
-  if (const char* pl = std::getenv("GMPNP_WARM_START")) s->warm_start = std::atoi(pl);
-  if (const char* pl = std::getenv("GMPNP_DIRECT_FALLBACK")) s->direct_fallback = std::atoi(pl);
-  if (const char* pl = std::getenv("GMPNP_PHASE_TIMING")) s->phase_timing = std::atoi(pl) != 0;
-  if (const char* pl = std::getenv("GMPNP_BAND_LU_MAX_GB")) s->lu_max_gb = std::atof(pl);
-  {  // fused launch form only where every workgroup of a launch is resident at once (3 x 512 threads per CU): there the
-     // hand-over inside the launch beats a launch boundary (+5 % on L_50_R_5); with more tiles than slots it loses (-4 %)
+  {  // Two launches per iteration (coarse workgroups inside the tile launch, tile workgroups wait for their flags) only
+     // where the runtime's occupancy figure proves the whole launch resident at once: a waiting workgroup must never
+     // keep the workgroup it waits for off the machine.  Not on a device the caller shares with other work.
     hipDeviceProp_t prop{};
     HIP_TRY(hipGetDeviceProperties(&prop, s->opts.device_id));
-    s->fused_half = mesh->dim == 3 && (s->t.ntiles + s->t.nagg) <= 3 * prop.multiProcessorCount;
+    int occ_a = 0, occ_b = 0;
+    if (mesh->dim == 3) {
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_half_a<9>, kKrylovThreads, 0));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, k_half_b<9>, kKrylovThreads, 0));
+    }
+    s->resident_slots = std::min(occ_a, occ_b) * prop.multiProcessorCount;
+    const bool resident = mesh->dim == 3 && (s->t.ntiles + s->t.nagg) <= s->resident_slots;
+    if (po.launch_form == 2 && (!resident || po.shared_device)) {
+      char buf[200];
+      snprintf(buf, sizeof buf, "launch_form 2 refused: %d workgroups per launch, %d resident at once (%d per CU x %d CUs)%s",
+               s->t.ntiles + s->t.nagg, s->resident_slots, std::min(occ_a, occ_b), prop.multiProcessorCount,
+               po.shared_device ? ", device declared shared" : "");
+      return fail(GMPNP_ERR_INVALID, buf);
+    }
+    s->fused_half = po.launch_form == 4 ? false : (resident && !po.shared_device);
   }
-  if (const char* pl = std::getenv("GMPNP_FUSED_HALF")) s->fused_half = std::atoi(pl) != 0;
   HIP_TRY(hipHostMalloc((void**)&s->h_part, 3 * std::max(s->n_resblocks, 1) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped));
   *s->h_status = 0;
@@ -1496,7 +1490,8 @@ int gmpnp_event_overhead(gmpnp_solver* s, int32_t pairs, double* mean_us) {
   return GMPNP_OK;
 }
 
-// debug only (not declared in gmpnp.h): resident workgroups per CU of the fused 3D Krylov kernels
+#ifdef GMPNP_DEV_HOOKS  // development builds only (tools/): not part of the ABI, not in the shipped library
+// resident workgroups per CU of the fused 3D Krylov kernels
 int gmpnp_debug_occupancy(int* out4) {
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[0], k_bicg_a<9>, kKrylovThreads, 0));
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out4[1], k_bicg_b<9>, kKrylovThreads, 0));
@@ -1533,6 +1528,7 @@ int gmpnp_debug_read(gmpnp_solver* s, int which, double* out, int64_t n) {
   HIP_TRY(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDeviceToHost));
   return (int)0;
 }
+#endif  // GMPNP_DEV_HOOKS
 
 int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched) {
   if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");

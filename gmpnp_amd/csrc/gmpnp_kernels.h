@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(kVecBlock) void k_true_residual(const double* __res
   if (threadIdx.x == 0) part[blockIdx.x] = w[0];
 }
 
-// Line search of a warm start: partials of (w,b), (w,w), (b,b) with w = J d (from k_spmv_plain), three per workgroup.
+// Test of a warm start: partials of (w,b), (w,w), (b,b) with w = J x0 (from k_spmv_plain), three per workgroup.
 __global__ __launch_bounds__(kVecBlock) void k_dots3(const double* __restrict__ w, const double* __restrict__ b,
                                                      double* __restrict__ part, int n, int nblocks) {
   __shared__ double lds[12];
@@ -1646,16 +1646,10 @@ __global__ __launch_bounds__(kVecBlock) void k_dots3(const double* __restrict__ 
   block_sum<3>(v, lds);
   if (threadIdx.x == 0) { part[blockIdx.x] = v[0]; part[nblocks + blockIdx.x] = v[1]; part[2 * nblocks + blockIdx.x] = v[2]; }
 }
-// x0 = theta d, r0 = b - theta w
-__global__ void k_line_apply(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ b,
-                             const double* __restrict__ w, double theta, int n) {
+// start of a warm solve: r0 = b - w with w = J x0 (x0 stays in kx)
+__global__ void k_start_residual(double* __restrict__ r, const double* __restrict__ b, const double* __restrict__ w, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { x[i] *= theta; r[i] = b[i] - theta * w[i]; }
-}
-// step = a - b (total update of a Newton solve, kept as the search direction of the next step's first linear solve)
-__global__ void k_diff(double* __restrict__ d, const double* __restrict__ a, const double* __restrict__ b, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) d[i] = a[i] - b[i];
+  if (i < n) r[i] = b[i] - w[i];
 }
 
 // file vertex order <-> internal order on the device (device-pointer entry points of the partitioned solve)

@@ -52,7 +52,7 @@ def run_job(radius_nm, voltage, num_steps, concentration_elec=0.5, device_id=0, 
     try:
         run = PoreRun(num_steps=num_steps, concentration_elec=concentration_elec, L=50e-9, R=radius_nm * 1e-9,
                       voltage_multiplier=ramp_value(voltage, 0, ramp_steps), as_published=as_published,
-                      device_kwargs={"device_id": device_id, "use_graph": False})
+                      device_kwargs={"device_id": device_id})
         out.update(n_vertices=run.mesh.num_vertices, n_dofs=run.problem.ndof)
         for n in range(num_steps):
             run.step(verbose=False)

@@ -140,15 +140,32 @@ typedef struct {
   double rhs_norm;
 } gmpnp_linear_stats_t;
 
-/* Creation-time tunables (no reference counterpart). Zero-initialise for defaults. */
+/* Creation-time tunables (no reference counterpart). Zero-initialise for defaults: every field's 0 is the default. */
 typedef struct {
   int32_t device_id;      /* HIP device ordinal */
   int32_t n_aggregates;   /* coarse-space slabs; 0 = default (8; at most 16 and what the LDS-resident coarse inverse allows) */
-  int32_t use_graph;      /* reserved (the Krylov launches carry the iteration index as an argument: eager only) */
+  int32_t shared_device;  /* 1 = other handles or processes use this GPU at the same time: no in-launch hand-over (four
+                             launches per BiCGStab iteration) and no second HIP stream */
   int32_t krylov_batch;   /* iterations of the first burst of a BiCGStab solve; 0 = default (sized from the
                              previous solves; afterwards the host keeps one iteration queued ahead of the progress
                              the kernels report into pinned memory) */
   int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */
+  int32_t launch_form;    /* launches per BiCGStab iteration: 0 = automatic (2 when hipOccupancyMaxActiveBlocksPerMultiprocessor
+                             proves every workgroup of a launch resident at once, else 4), 2, 4.  Asking for 2 on a
+                             problem that is not resident is refused (GMPNP_ERR_INVALID). */
+  int32_t warm_start;     /* start of Newton iteration k+1's linear solve: 0 = second-order prediction from the two previous
+                             corrections (default), 1 = first order, -1 = zero */
+  int32_t coarse_refresh; /* coarse operator: 0 = rebuilt every Newton iteration on the side stream and adopted one iteration
+                             later (default), N > 0 = rebuilt in the main stream every Nth Newton iteration */
+  int32_t progress_by_copy; /* 1 = the host polls BiCGStab with a device-to-host copy + event per burst instead of the
+                               pinned progress mirror */
+  int32_t burst_iterations; /* iterations queued per poll after the first burst; 0 = 1 */
+  int32_t phase_timing;   /* 1 = fill ms_assemble / ms_setup / ms_krylov of the Newton statistics (five event records
+                             and one wait more per iteration) */
+  int32_t no_direct_fallback; /* 1 = a 3D Krylov solve that does not converge is an error instead of a block-banded LU solve */
+  int32_t warm_in_stream; /* 1 = the test of the predicted start runs in the main stream behind the set-up */
+  int32_t reserved_[3];   /* zero */
+  double band_lu_max_gb;  /* largest band storage the direct solver may allocate; 0 = 48 */
 } gmpnp_options_t;
 
 typedef struct gmpnp_solver gmpnp_solver;

@@ -226,7 +226,7 @@ def test_newton_with_band_lu_matches_golden(case, L, nsteps, gpu_lib, monkeypatc
     from gmpnp_amd.pore3d import PoreRun
     g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
     if case == "pore50":
-        monkeypatch.setenv("GMPNP_3D_DIRECT", "1")
+        monkeypatch.setenv("GMPNP_3D_DIRECT", "1")   # read by the Python option translation (backend.newton_options)
     run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=L, R=5e-9, solver_parameters=BAND_09 if case == "pore10" else None)
     try:
         for k in range(nsteps):
@@ -240,7 +240,7 @@ def test_newton_with_band_lu_matches_golden(case, L, nsteps, gpu_lib, monkeypatc
 def test_krylov_failure_falls_back_to_band_lu(pore10, gpu_lib, monkeypatch):
     """The reference's linear solver is direct and cannot fail to converge; a BiCGStab solve that does (here: an
     iteration cap of 3) hands the system to the block-banded LU, and the Newton iterates stay those of the golden
-    steps.  GMPNP_DIRECT_FALLBACK=0 turns the failure back into the error it used to be."""
+    steps.  gmpnp_options_t.no_direct_fallback turns the failure back into the error it used to be."""
     from gmpnp_amd.solver import GMPNPSystem
     prob = pore10[2]
     g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
@@ -254,8 +254,7 @@ def test_krylov_failure_falls_back_to_band_lu(pore10, gpu_lib, monkeypatch):
         assert relerr(s.dev.get_state(), g["states"][0]) < 1e-8
     finally:
         s.close()
-    monkeypatch.setenv("GMPNP_DIRECT_FALLBACK", "0")
-    s = GMPNPSystem(prob)
+    s = GMPNPSystem(prob, no_direct_fallback=1)
     try:
         s.initialise([1.0] * 8 + [0.0])
         with pytest.raises(RuntimeError, match="BiCGStab stopped without convergence"):
@@ -564,14 +563,10 @@ def test_refined_mesh_uses_the_large_mesh_paths(gpu_lib):
         assert np.allclose(r[3:] / r[2:-1], 0.1, rtol=0.3)
 
 
-def _run_pore10(monkeypatch, nsteps=3, **env):
+def _run_pore10(nsteps=3, **options):
+    """`options`: fields of gmpnp_options_t (include/gmpnp.h)."""
     from gmpnp_amd.pore3d import PoreRun
-    for k in ("GMPNP_FUSED_HALF", "GMPNP_WARM_START", "GMPNP_COARSE_LAG", "GMPNP_HOST_POLL", "GMPNP_GRAPH_ITERS", "GMPNP_PHASE_TIMING",
-              "GMPNP_COARSE_ASYNC", "GMPNP_WARM_ASYNC"):
-        monkeypatch.delenv(k, raising=False)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)  # read by gmpnp_create
-    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=10e-9, R=5e-9)
+    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=10e-9, R=5e-9, device_kwargs=options)
     try:
         run.run(verbose=False)
         return np.array(run.history[1:]), list(run.newton_its), run.sys.dev.krylov_launches_per_iteration
@@ -579,27 +574,106 @@ def _run_pore10(monkeypatch, nsteps=3, **env):
         run.sys.close()
 
 
-def test_solver_variants_agree(monkeypatch, gpu_lib):
+def test_solver_variants_agree(gpu_lib):
     """The launch form must not change a single bit (same arithmetic, different hand-over); warm starts and coarse reuse
     change the Krylov path only: Newton counts identical, states equal to the linear-solve tolerance."""
-    ref, its, launches = _run_pore10(monkeypatch)
-    assert launches == 2  # L_10_R_5: every workgroup of a launch is resident
-    unfused, its_u, launches_u = _run_pore10(monkeypatch, GMPNP_FUSED_HALF="0")
+    ref, its, launches = _run_pore10()
+    assert launches == 2  # L_10_R_5: every workgroup of a launch is resident (occupancy query at create)
+    unfused, its_u, launches_u = _run_pore10(launch_form=4)
     assert launches_u == 4 and its_u == its and np.array_equal(unfused, ref)
-    cold, its_c, _ = _run_pore10(monkeypatch, GMPNP_WARM_START="0", GMPNP_COARSE_LAG="1", GMPNP_COARSE_ASYNC="0")
+    shared, its_sh, launches_sh = _run_pore10(shared_device=1)   # no in-launch hand-over, no side stream
+    assert launches_sh == 4 and its_sh == its and relerr(shared.ravel(), ref.ravel()) < 1e-8
+    cold, its_c, _ = _run_pore10(warm_start=-1, coarse_refresh=1)
     assert its_c == its and relerr(cold.ravel(), ref.ravel()) < 1e-8
+    first_order, its_f, _ = _run_pore10(warm_start=1)
+    assert its_f == its and relerr(first_order.ravel(), ref.ravel()) < 1e-8
     # coarse operator rebuilt in the main stream every third iteration instead of on the side stream: another valid
     # preconditioner, same Newton path; and the side-stream scheme is deterministic (events order the two streams)
-    sync3, its_s, _ = _run_pore10(monkeypatch, GMPNP_COARSE_ASYNC="0")
+    sync3, its_s, _ = _run_pore10(coarse_refresh=3)
     assert its_s == its and relerr(sync3.ravel(), ref.ravel()) < 1e-8
-    again, its_a, _ = _run_pore10(monkeypatch)
+    again, its_a, _ = _run_pore10()
     assert its_a == its and np.array_equal(again, ref)
     # how the host learns about progress (pinned mirror or copy + event), how many iterations it queues per poll and
     # whether the phases are timed changes no arithmetic at all
-    for env in (dict(GMPNP_HOST_POLL="0"), dict(GMPNP_GRAPH_ITERS="3"), dict(GMPNP_PHASE_TIMING="1"), dict(GMPNP_WARM_ASYNC="0"),
-                dict(GMPNP_HOST_POLL="0", GMPNP_FUSED_HALF="0")):
-        other, its_o, _ = _run_pore10(monkeypatch, **env)
-        assert its_o == its and np.array_equal(other, ref), env
+    for opt in (dict(progress_by_copy=1), dict(burst_iterations=3), dict(phase_timing=1), dict(warm_in_stream=1),
+                dict(progress_by_copy=1, launch_form=4)):
+        other, its_o, _ = _run_pore10(**opt)
+        assert its_o == its and np.array_equal(other, ref), opt
+
+
+def test_in_launch_handover_needs_proven_residency(pore50, gpu_lib):
+    """The two-launch form (tile workgroups wait inside the launch for flags raised by the coarse workgroups of the same
+    launch) is only enabled when hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs covers the whole grid.  Asking for
+    it on the once-refined L_50_R_5 mesh (about 3,700 tiles against at most 3 x 256 resident workgroups) is refused at
+    create instead of left to the kernels' time-out; the default falls back to four launches there, and a device
+    declared shared never gets the hand-over."""
+    pp, mesh, prob, bnd = pore50
+    with gpu_lib.DeviceSolver(prob) as dev:
+        assert dev.krylov_launches_per_iteration == 2
+    with gpu_lib.DeviceSolver(prob, shared_device=1) as dev:
+        assert dev.krylov_launches_per_iteration == 4
+    with pytest.raises(gpu_lib.GmpnpError, match="launch_form 2 refused"):
+        gpu_lib.DeviceSolver(prob, shared_device=1, launch_form=2)
+    from gmpnp_amd.problem import pore_problem
+    fprob, _ = pore_problem(pp, mesh, refine=1)
+    with pytest.raises(gpu_lib.GmpnpError, match="launch_form 2 refused"):
+        gpu_lib.DeviceSolver(fprob, launch_form=2)
+    with gpu_lib.DeviceSolver(fprob) as dev:
+        assert dev.krylov_launches_per_iteration == 4
+
+
+def test_two_handles_on_one_device_run_concurrently_without_handover_timeouts(pore10, gpu_lib):
+    """Two handles driven from two host threads on the same GPU (what `sweep --jobs_per_gpu 2` does): both reach the golden
+    steps; a hand-over time-out (status bit 8) would end a BiCGStab solve with an error or send it to the direct fallback."""
+    import threading
+    from gmpnp_amd.pore3d import PoreRun
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    out = {}
+
+    def work(tag):
+        run = PoreRun(num_steps=3, concentration_elec=0.5, L=10e-9, R=5e-9, device_kwargs={"shared_device": 1})
+        try:
+            direct = 0
+            for _ in range(3):
+                direct += run.step(verbose=False)["direct_solves"]
+            out[tag] = (list(run.newton_its), np.array(run.history[1:]), direct)
+        except Exception as e:  # noqa: BLE001
+            out[tag] = e
+        finally:
+            run.sys.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        assert not isinstance(out[k], Exception), out[k]
+        its, hist, direct = out[k]
+        assert its == [int(v) for v in g["newton_its"][:3]] and direct == 0
+        assert relerr(hist.reshape(3, -1), g["states"][:3]) < 1e-8
+
+
+def test_non_finite_linear_systems_are_errors_not_answers(pore10, gpu_lib):
+    """A NaN right-hand side or matrix must end in GMPNP_ERR_LINEAR / GMPNP_ERR_NUMERIC, never in `converged` with a
+    NaN update (the true residual of a 'converged' recurrence used to be accepted when it was NaN)."""
+    pp, mesh, prob, _ = pore10
+    u, un = random_state(mesh.num_vertices, 8, seed=5)
+    with gpu_lib.DeviceSolver(prob, no_direct_fallback=1) as dev:
+        dev.set_state(u, un)
+        dev.assemble(True)
+        b = np.ones(prob.ndof)
+        b[17] = np.nan
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.linear_solve(b)
+        assert ei.value.code in (gpu_lib.ERR_LINEAR, gpu_lib.ERR_NUMERIC)
+        b[17] = np.inf
+        with pytest.raises(gpu_lib.GmpnpError):
+            dev.linear_solve(b)
+        ubad = u.copy()
+        ubad[9 * 40 + 2] = np.nan   # NaN state -> NaN residual: Newton must stop with a numeric error
+        dev.set_state(ubad, un)
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        assert ei.value.code in (gpu_lib.ERR_LINEAR, gpu_lib.ERR_NUMERIC)
 
 
 # field_OHP [V/nm] and eps_rel_OHP "obtained from solving the MPNP code", reference 1D/Stern_CO2ER.py:66-68 — the only

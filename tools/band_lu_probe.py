@@ -24,7 +24,7 @@ def relerr(a, b):
 
 if "accuracy" in what:
     for L, R in ((10e-9, 5e-9), (50e-9, 5e-9), (50e-9, 1e-9)):
-        run = PoreRun(num_steps=2, concentration_elec=0.5, L=L, R=R, device_kwargs={"use_graph": False})
+        run = PoreRun(num_steps=2, concentration_elec=0.5, L=L, R=R)
         run.step(verbose=False)
         dev = run.sys.dev
         F, _ = dev.assemble(True)
@@ -43,7 +43,7 @@ if "accuracy" in what:
 
 if "newton" in what:
     for sp, name in ((SOLVER_PARAMETERS, "two-level BiCGStab"), (BAND, "band LU")):
-        run = PoreRun(num_steps=3, concentration_elec=0.5, L=10e-9, R=5e-9, device_kwargs={"use_graph": False}, solver_parameters=sp)
+        run = PoreRun(num_steps=3, concentration_elec=0.5, L=10e-9, R=5e-9, solver_parameters=sp)
         t0 = time.perf_counter()
         its = []
         for n in range(3):
@@ -57,7 +57,7 @@ if "newton" in what:
         ref_states = states
 
 if "r1" in what:
-    run = PoreRun(num_steps=8, concentration_elec=0.5, L=50e-9, R=1e-9, device_kwargs={"use_graph": False})
+    run = PoreRun(num_steps=8, concentration_elec=0.5, L=50e-9, R=1e-9)
     try:
         for n in range(8):
             t0 = time.perf_counter()

@@ -1,6 +1,5 @@
 """Exploratory GPU check (not a test): compare HIP assembly / SpMV / solves with the oracle and time them."""
 import os, sys, time
-os.environ.setdefault("GMPNP_PHASE_TIMING", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
@@ -20,7 +19,7 @@ nv = mesh.num_vertices
 rng = np.random.default_rng(0)
 u = np.concatenate([rng.uniform(.5, 1.5, (nv, 8)), rng.uniform(-1, 0, (nv, 1))], axis=1).ravel()
 un = np.concatenate([rng.uniform(.5, 1.5, (nv, 8)), rng.uniform(-1, 0, (nv, 1))], axis=1).ravel()
-t = time.time(); dev = backend.DeviceSolver(prob); print("create %.3fs nagg=%d nblocks=%d" % (time.time() - t, dev.n_aggregates, dev.n_blocks))
+t = time.time(); dev = backend.DeviceSolver(prob, phase_timing=1); print("create %.3fs nagg=%d nblocks=%d" % (time.time() - t, dev.n_aggregates, dev.n_blocks))
 dev.set_state(u, un)
 t = time.time(); F, nrm = dev.assemble(True); print("assemble %.4fs norm %.10e" % (time.time() - t, nrm))
 Fo, Ao = O.assemble(prob, u, un)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gmpnp_amd.pore3d import PoreRun
 for na in (15, 12, 10, 8, 6):
-    run = PoreRun(num_steps=30, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"use_graph": False, "n_aggregates": na})
+    run = PoreRun(num_steps=30, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"n_aggregates": na})
     run.step(verbose=False)
     t0 = time.perf_counter()
     for _ in range(29): run.step(verbose=False)

@@ -1,11 +1,10 @@
 """Where a Newton iteration of the bench workload goes: device time of assembly / preconditioner set-up / Krylov
 (hipEvents inside gmpnp_newton_solve) against the wall clock of the solve and of the whole time step (GPU box)."""
 import os, sys, time
-os.environ.setdefault("GMPNP_PHASE_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gmpnp_amd.pore3d import PoreRun
 
-run = PoreRun(num_steps=52, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"use_graph": False})
+run = PoreRun(num_steps=52, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"phase_timing": 1})
 for _ in range(2):
     run.step(verbose=False)
 acc = dict(ms_assemble=0.0, ms_setup=0.0, ms_krylov=0.0, ms_total=0.0, iterations=0, krylov_iterations=0)

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gmpnp_amd.pore3d import PoreRun
 for na in (8,):
-    run = PoreRun(num_steps=8, concentration_elec=0.5, L=50e-9, R=1e-9, device_kwargs={"use_graph": False, "n_aggregates": na})
+    run = PoreRun(num_steps=8, concentration_elec=0.5, L=50e-9, R=1e-9, device_kwargs={"n_aggregates": na})
     out = []
     try:
         for n in range(8):

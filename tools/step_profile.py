@@ -8,7 +8,7 @@ ge.build()
 from gmpnp_amd.pore3d import PoreRun
 from gmpnp_amd.problem import pore_dirichlet
 from gmpnp_amd.solver import column_medians
-run = PoreRun(num_steps=20, concentration_elec=0.5, L=50e-9, R=5e-9, device_kwargs={"use_graph": False})
+run = PoreRun(num_steps=20, concentration_elec=0.5, L=50e-9, R=5e-9)
 T = {}
 def tic(name, t0):
     T[name] = T.get(name, 0.0) + time.perf_counter() - t0
