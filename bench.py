@@ -23,8 +23,9 @@ Extra objects on the JSON line:
                 16 nd; the vector traffic fused in is not counted) / mean kernel duration, sampled LIVE during the timed
                 region: every 32nd launch carries a start/stop HIP event pair attached to the dispatch itself
                 (hipExtLaunchKernelGGL on the solver's stream), i.e. the kernel's own begin-to-end time.
-  cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU, one thread) timed on rank 0 / N = 1 for ONE Newton
-                iteration of the same workload (about 20-30 s); kind = "port" (FEniCS itself cannot be installed).
+  cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU) timed on rank 0 / N = 1 over the first 3 Newton iterations
+                of the same window, on 1 thread and on all cores (about 35 s together); kind = "port" (FEniCS itself
+                cannot be installed).  `full_window_recorded` = the committed timing of the whole 50-step window.
 """
 import argparse
 import json
@@ -49,29 +50,45 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(run):
-    """One Newton iteration of time step 0 with the oracle (test infrastructure used here only as the timed CPU leg)."""
+def cpu_baseline(run, max_newton=3):
+    """Bounded sample of the CPU path: the first `max_newton` Newton iterations of time step 0 of
+    the SAME window with the oracle (test infrastructure, used here only as the timed CPU leg) — NumPy P1 assembly of the
+    exact Jacobian + SciPy SuperLU per iteration, damped update — once limited to 1 thread (the reference is a serial
+    process) and once with every core of the box (threadpoolctl; SuperLU itself is serial).  The whole 50-step window
+    takes the oracle about half an hour: tools/cpu_window.py times it, profiles/r02/cpu_window_*.json hold the result,
+    and tests/test_gpu_parity.py::test_bench_window_matches_golden pins the GPU's Newton count per step to the oracle's."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gmpnp_oracle as O
-    import scipy.sparse.linalg as spla
-    prob = run.problem
+    from threadpoolctl import threadpool_limits
+    import copy
+    prob = copy.copy(run.problem)
+    from gmpnp_amd.problem import pore_dirichlet
+    prob.bc_dofs, prob.bc_vals = pore_dirichlet(run.pp, run.bnd)   # the t = 0 Dirichlet set
     nv = run.mesh.num_vertices
-    u = np.zeros(prob.ndof)
+    u0 = np.zeros(prob.ndof)
     un = np.tile(np.r_[np.ones(8), 0.0], nv)
-    O.assemble(prob, u, un)  # builds the scatter pattern once (one-off set-up, like DOLFIN's sparsity pattern)
-    t0 = time.perf_counter()
-    b, A = O.assemble(prob, u, un, want_jacobian=True)
-    t1 = time.perf_counter()
-    dx = spla.splu(A.tocsc()).solve(b)
-    t2 = time.perf_counter()
-    u = u - 0.9 * dx
-    O.assemble(prob, u, un, want_jacobian=False)
-    t3 = time.perf_counter()
-    return {"value": 1.0 / (t3 - t0), "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
-            "sample": "1 Newton iteration of time step 0 (same mesh/parameters): NumPy P1 assembly of J and F "
-                      "%.1f s + SciPy SuperLU factor+solve %.1f s + residual re-assembly %.1f s; FEniCS/MUMPS "
-                      "itself is not installable on this box" % (t1 - t0, t2 - t1, t3 - t2),
-            "host_cpus": os.cpu_count()}
+    O.assemble(prob, u0, un)  # builds the scatter pattern once (one-off set-up, like DOLFIN's sparsity pattern)
+    legs = {}
+    for name, lim in (("one_thread", 1), ("all_cores", os.cpu_count() or 1)):
+        with threadpool_limits(limits=lim):
+            t0 = time.perf_counter()
+            _, st = O.newton_solve(prob, u0, un, maximum_iterations=max_newton, relaxation_parameter=0.9,
+                                   error_on_nonconvergence=False)
+            wall = time.perf_counter() - t0
+        legs[name] = {"threads": lim, "newton_iterations": st.iterations, "seconds": wall, "assembly_seconds": st.t_assemble,
+                      "lu_seconds": st.t_linear, "value": st.iterations / wall}
+    one = legs["one_thread"]
+    window = None
+    wpath = os.path.join(ROOT, "profiles", "r02", "cpu_window_1thread.json")
+    if os.path.exists(wpath):
+        with open(wpath) as fh:
+            window = json.load(fh)
+    return {"value": one["value"], "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
+            "sample": "first %d Newton iterations of time step 0 of the same window (same mesh/parameters, zero initial guess): "
+                      "NumPy P1 assembly of J and F %.1f s + SciPy SuperLU factor+solve %.1f s on 1 thread; FEniCS/MUMPS "
+                      "itself is not installable on this box" % (one["newton_iterations"], one["assembly_seconds"], one["lu_seconds"]),
+            "all_cores": legs["all_cores"], "one_thread": one, "host_cpus": os.cpu_count(),
+            "full_window_recorded": window}
 
 
 def main():
@@ -165,11 +182,16 @@ def main():
         else:
             kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_spmv_pmc.json")
+        # memory-side bytes per launch from the committed PMC passes; only valid for the build they were measured on
+        traffic, traffic_note = None, "no PMC file"
+        pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
         if os.path.exists(pmc) and a.mesh == "L_50_R_5" and a.refine == 0:
             with open(pmc) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+                pj = json.load(fh)
+            if pj.get("build_id") == dev.build_id and pj.get("launches_per_krylov_iteration") == launches:
+                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), pj.get("source")
+            else:
+                traffic_note = "profiles/spmv_pmc.json was measured on build %s, this library is %s: dropped" % (pj.get("build_id"), dev.build_id)
         out = {
             "metric": "newton_iterations_per_sec", "value": its / dt, "unit": "Newton-iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -184,7 +206,7 @@ def main():
                        "krylov_iterations": kry,
                        "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
                          "launches_per_krylov_iteration": launches},

@@ -23,7 +23,7 @@ LINEAR_TWOLEVEL, LINEAR_JACOBI, LINEAR_BLOCK_TRIDIAGONAL, LINEAR_BAND_LU = 0, 1,
 MAX_HISTORY = 64
 
 EXPORTS = [
-    "gmpnp_version", "gmpnp_last_error", "gmpnp_create", "gmpnp_destroy", "gmpnp_set_model",
+    "gmpnp_version", "gmpnp_build_id", "gmpnp_last_error", "gmpnp_create", "gmpnp_destroy", "gmpnp_set_model",
     "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
@@ -90,6 +90,7 @@ def load_library(path: str = None):
     lib = ctypes.CDLL(p)
     lib.gmpnp_version.restype = ctypes.c_char_p
     lib.gmpnp_last_error.restype = ctypes.c_char_p
+    lib.gmpnp_build_id.restype = ctypes.c_char_p
     lib.gmpnp_create.argtypes = [POINTER(CMesh), POINTER(CModel), POINTER(CQuadrature), POINTER(COptions),
                                  POINTER(c_void_p)]
     lib.gmpnp_destroy.argtypes = [c_void_p]
@@ -265,6 +266,10 @@ class DeviceSolver:
         self.close()
 
     # ------------------------------------------------------------------------------------------
+    @property
+    def build_id(self):
+        return self.lib.gmpnp_build_id().decode()
+
     @property
     def n_blocks(self):
         return int(self.lib.gmpnp_n_blocks(self._h))

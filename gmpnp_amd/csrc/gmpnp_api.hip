@@ -964,7 +964,11 @@ int export_dev(gmpnp_solver* s, const double* internal, double* file_order_dev) 
 // =================================================================================================
 extern "C" {
 
-const char* gmpnp_version(void) { return "gmpnp-mi355x 0.1 (gfx950)"; }
+#ifndef GMPNP_BUILD_ID
+#define GMPNP_BUILD_ID "unstamped"
+#endif
+const char* gmpnp_version(void) { return "gmpnp-mi355x 0.2 (gfx950)"; }
+const char* gmpnp_build_id(void) { return GMPNP_BUILD_ID; }
 const char* gmpnp_last_error(void) { return g_err.c_str(); }
 
 int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,

@@ -119,6 +119,18 @@ class EDLRun:
             self.step(verbose)
         return self
 
+    def ohp_summary(self):
+        """field_OHP [V/nm] and eps_rel_OHP of the current state, as the reference derives them for metadata.json
+        (1D:802-805 projection of -grad(p), 1D:893-954 rescaling): the two quantities 1D/Stern_CO2ER.py:66-68 records."""
+        ep, mesh = self.ep, self.mesh
+        last = self.history[-1]
+        field = project_gradient(mesh.coords, mesh.cells, last[:, 6], sign=-1.0)[:, 0] * ep.thermal_voltage / ep.L_n
+        c_cat = last[0, 5] * ep.initial_conc[ep.cation]
+        c_H = last[0, 0] * ep.initial_conc["H"]
+        w = (ep.n_water[ep.cation] * c_cat + ep.n_water["H"] * c_H) * 1.0e-3
+        return {"field_OHP": float(field[0] * 1.0e-9), "eps_rel_OHP": float(ep.eps_rel * ((55 - w) / 55) + 6 * (w / 55)),
+                "potential_OHP": float(last[0, 6] * ep.thermal_voltage)}
+
     def write_outputs(self, stamp=None):
         ep, mesh, k = self.ep, self.mesh, self.kwargs
         stamp = stamp or datetime.now().strftime("%y-%m-%d-%H-%M-%S")

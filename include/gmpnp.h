@@ -171,6 +171,9 @@ typedef struct {
 typedef struct gmpnp_solver gmpnp_solver;
 
 const char* gmpnp_version(void);
+/* First 16 hex digits of the SHA-256 over the library's native sources (stamped by the build recipe, __graft_entry__.build):
+ * measurements kept in the repository (PMC traffic per launch) name the build they were taken on. */
+const char* gmpnp_build_id(void);
 /* Message of the most recent failure on this thread. */
 const char* gmpnp_last_error(void);
 

@@ -12,6 +12,13 @@ EXTRA_PORE = {
     # thinnest pore of the sweep (BASELINE configs[4]): from time step 3 on BiCGStab no longer converges and the
     # block-banded LU takes over, as MUMPS does in the reference
     "pore50_r1": (dict(concentration_elec=0.5, L=50e-9, R=1e-9), 6),
+    # the other radii of the sweep (BASELINE configs[4]) at V = -1.  R = 2.5 nm loads the R = 2 nm mesh (the reference
+    # builds the file name with int(): SURVEY Q4) with the R = 2.5 nm scaling and marking radius; R = 7.5 nm asks for
+    # L_50_R_7.xml, which does not exist (tests assert the error).
+    "pore50_r2": (dict(concentration_elec=0.5, L=50e-9, R=2e-9), 2),
+    "pore50_r2p5": (dict(concentration_elec=0.5, L=50e-9, R=2.5e-9), 2),
+    "pore50_r4": (dict(concentration_elec=0.5, L=50e-9, R=4e-9), 2),
+    "pore50_r10": (dict(concentration_elec=0.5, L=50e-9, R=10e-9), 2),
 }
 
 EXTRA_EDL = {

@@ -330,6 +330,59 @@ def test_edl_time_loop_matches_golden(case, kw, nsteps, gpu_lib):
         run.sys.close()
 
 
+def test_bench_window_matches_golden(gpu_lib):
+    """bench.py's metric is a COUNT of Newton iterations over time steps 0..49 of BASELINE configs[2]: the GPU's
+    BiCGStab@1e-10 solves must give the direct-solve oracle's count at EVERY step of that window, its residual history,
+    its Sechenov feedback and its states (tests/golden/pore50_window.npz, tools/make_golden_window.py)."""
+    from gmpnp_amd.pore3d import PoreRun
+    g = np.load(os.path.join(GOLDEN, "pore50_window.npz"))
+    nsteps = len(g["newton_its"])
+    assert nsteps == 50
+    run = PoreRun(num_steps=nsteps, concentration_elec=0.5, L=50e-9, R=5e-9)
+    try:
+        co2, res = [], []
+        for k in range(nsteps):
+            st = run.step(verbose=False)
+            co2.append(run.co2_bc)
+            res.append(st["residuals"])
+        assert run.newton_its == [int(v) for v in g["newton_its"]]
+        assert int(np.sum(run.newton_its)) == int(g["newton_its"].sum())
+        H = np.array(run.history[1:])                      # (steps, nv, 9)
+        assert np.allclose(np.array(co2), g["co2_bc"], rtol=1e-9, atol=0)
+        for k in range(nsteps):
+            gr = g["residuals"][k][: len(res[k])]
+            # residual norms: the entries that decide the stopping test sit at 1e-4 relative, where the 1e-10 linear
+            # solves leave ~1e-6 relative differences
+            assert len(res[k]) == int(np.sum(np.isfinite(g["residuals"][k]))) and np.allclose(res[k], gr, rtol=1e-4), k
+        assert relerr(H[:, g["probes"], :].ravel(), g["probe_values"].ravel()) < 1e-8
+        assert np.allclose(np.sqrt((H ** 2).sum(axis=1)), g["field_norms"], rtol=1e-8)
+        for k, full in zip(g["full_steps"], g["full_states"]):
+            assert relerr(H[int(k)].ravel(), full) < 1e-8
+    finally:
+        run.sys.close()
+
+
+def test_config0_diverges_on_the_gpu_as_in_the_oracle(gpu_lib):
+    """BASELINE configs[0] (1 um mesh, Cs, V = -10): the undamped Newton of the first time step fails on the GPU as it
+    does in the oracle (tests/test_oracle.py::test_config0_first_newton_solve_diverges_in_the_oracle); the driver raises
+    the RuntimeError DOLFIN raises.  V = -5 on the same mesh converges (golden edl1)."""
+    from gmpnp_amd.edl1d import EDLRun
+    run = EDLRun(num_steps=1, L_n=1e-6, cation="Cs", voltage_multiplier=-10.0)
+    try:
+        with pytest.raises(RuntimeError):
+            run.step(verbose=False)
+    finally:
+        run.sys.close()
+
+
+def test_sweep_radius_7p5_inherits_the_mesh_name_bug(gpu_lib):
+    """configs[4] lists R = 7.5 nm; the reference builds 'L_50_R_7.xml' with int() (3D:330-331), a file that
+    does not exist: same failure here, before anything touches the GPU."""
+    from gmpnp_amd.pore3d import PoreRun
+    with pytest.raises((FileNotFoundError, OSError, RuntimeError), match="L_50_R_7"):
+        PoreRun(num_steps=1, concentration_elec=0.5, L=50e-9, R=7.5e-9)
+
+
 def test_full_size_properties(pore50, gpu_lib):
     """Size-independent properties on the north-star mesh: Newton reduces the residual monotonically once the bc rows
     are absorbed, the update direction satisfies J dx = b, two handles give bitwise-identical results, and the driver
@@ -688,9 +741,9 @@ STERN_OHP = {-2.5: (-0.08032108300135771, 74.56149297894756), -5.0: (-0.25244154
 def test_reference_recorded_ohp_field_and_permittivity(voltage, tmp_path, monkeypatch, gpu_lib):
     """End-to-end pin of the product path on reference-held data: the 1D driver (GPU Newton/time loop, then the
     consistent-mass projection of -grad(p) and the rescaling of 1D:802-805,893-954) run through its CLI reproduces
-    the recorded OHP field to 1 % and the recorded OHP permittivity to 0.3 %.  After 300 steps the field is within
-    0.1-0.6 % and still creeping towards the recorded value (the diffusion layer keeps evolving; the author's run
-    length is not recorded), the permittivity is settled."""
+    the recorded OHP field to 1 % and the recorded OHP permittivity to 0.3 % after 300 steps.  The remaining gap is RUN
+    LENGTH only: the recorded numbers belong to the 20,000-solve staged schedule, which reproduces them to 1e-10
+    (test_staged_schedule_reproduces_the_recorded_digits)."""
     import json
     monkeypatch.setenv("GMPNP_OUT", str(tmp_path))
     from gmpnp_amd import edl1d
@@ -699,6 +752,33 @@ def test_reference_recorded_ohp_field_and_permittivity(voltage, tmp_path, monkey
     field, eps = STERN_OHP[voltage]
     assert abs(meta["field_OHP"] / field - 1.0) < 0.01
     assert abs(meta["eps_rel_OHP"] / eps - 1.0) < 0.003
+
+
+@pytest.mark.parametrize("voltage", [-2.5, -7.5])
+def test_staged_schedule_reproduces_the_recorded_digits(voltage, gpu_lib):
+    """The reference's FULL 1D schedule (1D:273-290: 10,000 steps of 1e-5 s, then 10,000 steps whose clock advances by
+    1e-3 s while the form keeps dt = 1e-5 s) on the GPU, post-processed as the reference does (1D:802-805,
+    893-954), lands on the digits 1D/Stern_CO2ER.py:66-68 records: measured 4e-13 / 5e-14 (V = -2.5), 2e-11 / 7e-12
+    (-5), 1.5e-10 / 2e-11 (-7.5), 4e-12 / 6e-14 (-10) relative for field_OHP / eps_rel_OHP
+    (profiles/r02/stern_schedule.json; tools/stern_schedule.py runs all five).  Newton stops at 1e-4, so agreement at
+    1e-10 after 20,000 solves means the iterates themselves follow FEniCS's: forms, scaling, Gauss-Legendre rules of the
+    steric term (2 points in F, 3 in J), DOLFIN's Newton/BC semantics, the direct solve and the projection are pinned
+    for the 1D MPNP path.  V = -12.5 is not in the test: there Newton's residual wanders at 5e-4 ... 4e-3 around the
+    1e-4 relative target (oracle and GPU alike) and reaching it within 50 iterations is a lottery per step that this
+    run loses at step 6,000 of 20,000 (profiles/r02/stern_v125_probe.log)."""
+    from gmpnp_amd.edl1d import EDLRun
+    field, eps = STERN_OHP[voltage]
+    run = EDLRun(voltage_multiplier=voltage, dry_run=False)
+    try:
+        assert run.tot_num_steps == 20000
+        for _ in range(run.tot_num_steps):
+            run.step(verbose=False)
+            run.history = run.history[-1:]
+        s = run.ohp_summary()
+    finally:
+        run.sys.close()
+    assert abs(s["field_OHP"] / field - 1.0) < 2e-9, s
+    assert abs(s["eps_rel_OHP"] / eps - 1.0) < 2e-10, s
 
 
 def _partition_worker(rank, world, port, out_dir, resident=False):

@@ -246,3 +246,23 @@ def test_supg_parameters_product_side_equals_oracle(edl1):
     on_large = (r_orac != small).any(axis=1)
     assert on_large.any() and (~on_large).any() and not r_orac[:, 4].any()  # both branches; CO2 (z = 0) untouched
     assert np.allclose(project_cellwise(mesh.coords, mesh.cells, np.full(len(mesh.cells), 3.0)), 3.0)
+
+
+def test_config0_first_newton_solve_diverges_in_the_oracle():
+    """BASELINE configs[0] (1 um mesh, Cs, voltage_multiplier = -10, README example shape): the UNDAMPED Newton of the
+    reference's 1D script (relaxation 1.0, 1D:357-364) started from u = 0 does not converge within 50 iterations on this
+    mesh in the oracle; DOLFIN would raise the same RuntimeError.  (V = -5 on the same mesh and V = -10 on the 50 um
+    mesh converge: goldens edl1 / edl50.)  Whether FEniCS itself survives that step cannot be checked here."""
+    import warnings
+    from conftest import _edl
+    ep, mesh, prob = _edl(L_n=1e-6, cation="Cs", voltage_multiplier=-10.0)
+    nv = mesh.num_vertices
+    u0, un = np.zeros(prob.ndof), np.tile(np.r_[np.ones(6), 0.0], nv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, st = O.newton_solve(prob, u0, un, relaxation_parameter=1.0, error_on_nonconvergence=False)
+        with pytest.raises(RuntimeError, match="did not converge"):
+            O.newton_solve(prob, u0, un, relaxation_parameter=1.0)
+    r = np.array(st.residuals)
+    assert not st.converged and st.iterations == 50
+    assert not np.all(np.isfinite(r)) or r[-1] > 1e-2 * r[0]   # nowhere near the 1e-4 tolerances

@@ -1,0 +1,55 @@
+"""CPU leg of the headline comparison over the WHOLE bench window: the first K time steps of
+BASELINE configs[2] (L_50_R_5, 0.5 M, K+, V = -1) with the CPU oracle — NumPy P1 assembly of residual + exact Jacobian,
+SciPy SuperLU per Newton iteration (the algorithm class of the reference's MUMPS solve, 3D:792), damped update, the
+reference's stopping rule and per-step Sechenov feedback — timed on this box's host cores.
+
+    python tools/cpu_window.py --steps 50 --threads 1 --out profiles/r02/cpu_window_1thread.json
+
+Prints / stores Newton iterations per second over the solve phase, split into assembly and LU time, and the Newton
+iteration count per step (the GPU run of the same window must give the same counts).  FEniCS itself is not installable.
+"""
+import argparse, json, os, sys, time
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--threads", type=int, default=1, help="BLAS/OpenMP threads (0 = all cores)")
+ap.add_argument("--out", type=str, default=None)
+a = ap.parse_args()
+nthreads = a.threads if a.threads > 0 else (os.cpu_count() or 1)
+for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[k] = str(nthreads)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import gmpnp_oracle as O
+from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+from gmpnp_amd.params import pore_parameters, utilities_dir
+from gmpnp_amd.problem import pore_problem, pore_dirichlet
+
+pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
+mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+prob, bnd = pore_problem(pp, mesh)
+nv, nf = mesh.num_vertices, prob.nf
+u = np.zeros(prob.ndof)
+un = np.tile(np.r_[np.ones(nf - 1), 0.0], nv)
+O.assemble(prob, u, un)   # scatter pattern, once (DOLFIN builds its sparsity pattern once, too)
+its, t_asm, t_lu = [], 0.0, 0.0
+t0 = time.perf_counter()
+for n in range(a.steps):
+    u, st = O.newton_solve(prob, u, un, maximum_iterations=50, relative_tolerance=1e-4, absolute_tolerance=1e-4, relaxation_parameter=0.9)
+    u2 = u.reshape(nv, nf)
+    co2 = pp.sechenov_co2_scaled(np.median(u2[:, 1]), np.median(u2[:, 2]), np.median(u2[:, 3]), np.median(u2[:, 7]))
+    prob.bc_dofs, prob.bc_vals = pore_dirichlet(pp, bnd, co2)
+    un = u.copy()
+    its.append(st.iterations); t_asm += st.t_assemble; t_lu += st.t_linear
+    print("step %d: %d Newton iterations, %.1f s so far" % (n, st.iterations, time.perf_counter() - t0), flush=True)
+wall = time.perf_counter() - t0
+out = {"workload": "3D MPNP_CO2ER_pore L_50_R_5, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0" % (a.steps - 1),
+       "kind": "port (CPU oracle: NumPy assembly + SciPy SuperLU; FEniCS/MUMPS not installable)",
+       "threads": nthreads, "host_cpus": os.cpu_count(), "steps": a.steps, "newton_iterations": int(sum(its)),
+       "newton_per_step": its, "seconds": wall, "assembly_seconds": t_asm, "lu_seconds": t_lu,
+       "value": sum(its) / wall, "unit": "Newton-iterations/s"}
+print(json.dumps(out))
+if a.out:
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    with open(a.out, "w") as fh:
+        json.dump(out, fh, indent=1)
