@@ -29,7 +29,10 @@ EXPORTS = [
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
     "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
+    "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_destroy", "gmpnp_group_create",
+    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
 ]
+COMM_ID_BYTES = 128
 
 
 class CMesh(ctypes.Structure):
@@ -67,6 +70,15 @@ class COptions(ctypes.Structure):
                 ("warm_start", c_int32), ("coarse_refresh", c_int32), ("progress_by_copy", c_int32),
                 ("burst_iterations", c_int32), ("phase_timing", c_int32), ("no_direct_fallback", c_int32),
                 ("warm_in_stream", c_int32), ("reserved_", c_int32 * 3), ("band_lu_max_gb", c_double)]
+
+
+class CPartition(ctypes.Structure):
+    """gmpnp_partition_t (include/gmpnp.h)."""
+    _fields_ = [("rank", c_int32), ("size", c_int32), ("n_global_aggregates", c_int32),
+                ("vertex_aggregate", POINTER(c_int32)), ("vertex_owned", POINTER(ctypes.c_uint8)),
+                ("n_neighbours", c_int32), ("neighbour_rank", POINTER(c_int32)),
+                ("send_ptr", POINTER(c_int32)), ("send_vertices", POINTER(c_int32)),
+                ("recv_ptr", POINTER(c_int32)), ("recv_vertices", POINTER(c_int32))]
 
 
 class GmpnpError(RuntimeError):
@@ -124,6 +136,17 @@ def load_library(path: str = None):
     lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
     lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
     lib.gmpnp_event_overhead.argtypes = [c_void_p, c_int32, POINTER(c_double)]
+    lib.gmpnp_create_partition.argtypes = [POINTER(CMesh), POINTER(CModel), POINTER(CQuadrature), POINTER(COptions),
+                                           POINTER(CPartition), POINTER(c_void_p)]
+    lib.gmpnp_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.gmpnp_comm_create.argtypes = [ctypes.c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+    lib.gmpnp_comm_destroy.argtypes = [c_void_p]
+    lib.gmpnp_comm_destroy.restype = None
+    lib.gmpnp_group_create.argtypes = [c_int32, POINTER(c_void_p), c_void_p, POINTER(c_void_p)]
+    lib.gmpnp_group_destroy.argtypes = [c_void_p]
+    lib.gmpnp_group_destroy.restype = None
+    lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
+    lib.gmpnp_group_assign_previous.argtypes = [c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -207,7 +230,7 @@ class DeviceSolver:
     """Device-resident GMPNP problem (one handle = one GPU, one HIP stream)."""
 
     def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, krylov_batch: int = 0,
-                 profile_every: int = 0, perm: np.ndarray = None, lib=None, **options):
+                 profile_every: int = 0, perm: np.ndarray = None, lib=None, partition: dict = None, **options):
         """``options``: further fields of ``gmpnp_options_t`` by name (shared_device, launch_form, warm_start,
         coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream,
         band_lu_max_gb); all default to 0."""
@@ -238,7 +261,21 @@ class DeviceSolver:
             setattr(opts, k, v)
         h = c_void_p()
         self._h = None
-        self._check(self.lib.gmpnp_create(byref(m), byref(cm), byref(cq), byref(opts), byref(h)))
+        if partition is None:
+            self._check(self.lib.gmpnp_create(byref(m), byref(cm), byref(cq), byref(opts), byref(h)))
+        else:  # one rank's handle of a mesh-partitioned solve (gmpnp_amd.dist.partition_plan builds the dict)
+            keep = {k: np.ascontiguousarray(partition[k], dtype=np.int32) for k in
+                    ("vertex_aggregate", "neighbour_rank", "send_ptr", "send_vertices", "recv_ptr", "recv_vertices")}
+            keep["vertex_owned"] = np.ascontiguousarray(partition["vertex_owned"], dtype=np.uint8)
+            self._partition_arrays = keep
+            cp = CPartition()
+            cp.rank, cp.size, cp.n_global_aggregates = int(partition["rank"]), int(partition["size"]), int(partition["n_global_aggregates"])
+            cp.vertex_aggregate = _iptr(keep["vertex_aggregate"])
+            cp.vertex_owned = keep["vertex_owned"].ctypes.data_as(POINTER(ctypes.c_uint8))
+            cp.n_neighbours = len(keep["neighbour_rank"])
+            cp.neighbour_rank, cp.send_ptr, cp.send_vertices = _iptr(keep["neighbour_rank"]), _iptr(keep["send_ptr"]), _iptr(keep["send_vertices"])
+            cp.recv_ptr, cp.recv_vertices = _iptr(keep["recv_ptr"]), _iptr(keep["recv_vertices"])
+            self._check(self.lib.gmpnp_create_partition(byref(m), byref(cm), byref(cq), byref(opts), byref(cp), byref(h)))
         self._h = h
         if len(problem.bc_dofs):
             self.set_dirichlet(problem.bc_dofs, problem.bc_vals)
@@ -399,6 +436,13 @@ class DeviceSolver:
             return stats
         self._check(code)
         return stats
+
+    @staticmethod
+    def stats_dict(st: "CNewtonStats"):
+        return {"iterations": st.iterations, "converged": bool(st.converged), "krylov_iterations": st.krylov_iterations,
+                "residuals": [st.residuals[i] for i in range(st.n_residuals)],
+                "krylov_per_iteration": [st.krylov_per_iteration[i] for i in range(min(st.iterations, MAX_HISTORY))],
+                "ms_total": st.ms_total, "direct_solves": st.direct_solves}
 
     def time_kernel(self, kernel: int, launches: int = 50) -> float:
         us = c_double()

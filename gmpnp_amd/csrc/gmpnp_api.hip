@@ -13,6 +13,7 @@
 
 #include "gmpnp_kernels.h"
 #include "gmpnp_band_lu.h"
+#include "gmpnp_dist_kernels.h"
 
 using namespace gmpnp;
 
@@ -131,6 +132,12 @@ struct gmpnp_solver {
   int direct_backoff = 0;       // length of the last such stretch (doubles with every new failure, resets on a converged Krylov solve)
   hipEvent_t ev_phase[6] = {};
   hipEvent_t ev_poll[2] = {};
+  // mesh partition (gmpnp_create_partition): halo plan in INTERNAL node ids, buffers of the fused exchanges
+  bool partitioned = false; int part_rank = 0, part_size = 1;
+  std::vector<int32_t> nb_rank, send_ptr, recv_ptr;   // neighbours; [n_neighbours + 1] offsets into the node lists
+  DevBuf<int32_t> send_nodes, recv_nodes;
+  DevBuf<double> sendbuf, recvbuf, red_i, red_a, red_b, red_norm;
+  double* h_red = nullptr;   // pinned [8]: all-reduced ||b||^2 and status bits
 
   ~gmpnp_solver() {
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -142,6 +149,7 @@ struct gmpnp_solver {
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_part) (void)hipHostFree(h_part);
     if (h_status) (void)hipHostFree(h_status);
+    if (h_red) (void)hipHostFree(h_red);
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
     if (ev_mat) (void)hipEventDestroy(ev_mat);
     if (ev_chain) (void)hipEventDestroy(ev_chain);
@@ -339,7 +347,7 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
   // sampled launches attach the events to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the kernel's
   // own begin-to-end time, the quantity rocprofv3's kernel trace reports
   if (s->fused_half) {
-    const dim3 fg(s->t.nagg + s->t.ntiles);
+    const dim3 fg(s->t.nagg + s->t.own_ntiles);
     const unsigned target = (unsigned)(++s->fused_seq);
     if (WHICH == 0) {
       if (ev) hipExtLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
@@ -350,12 +358,12 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
     }
   } else if (WHICH == 0) {
     hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
-    if (ev) hipExtLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-    else hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    if (ev) hipExtLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
+    else hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
   } else {
     hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
-    if (ev) hipExtLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-    else hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    if (ev) hipExtLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
+    else hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
   }
   s->spmv_launched++;
   return GMPNP_OK;
@@ -397,7 +405,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
   // one launch: shadow vector (r_0, or GMPNP_SHADOW_B=1 / a random vector after a breakdown), y = 0, P^T r_0 partials
   // where A(0) expects them, hand-over flags cleared, scalars from the kernel argument
-  hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->shadow_src, init, s->cpart_v1.p);
+  hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->shadow_src, init, s->cpart_v1.p);
   // the previous solve wrote its verdict before the host left its loop and nothing of it writes the mirror afterwards
   volatile HostPoll* hp = s->h_poll;
   hp->done = 0; hp->iters = 0; hp->rr = 0.0;
@@ -480,9 +488,10 @@ int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double
                const NewtonUpdate* upd = nullptr) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   if (s->c.use_coarse)
-    hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.ntiles), dim3(kVecBlock), 0, s->stream, s->c, src, s->cpart_v0.p);
-  hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, src,
-                     (const double*)s->cpart_v0.p, dst, scale_dst, scale_x, upd ? *upd : NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0});
+    hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, src, s->cpart_v0.p);
+  hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, src,
+                     (const double*)s->cpart_v0.p, dst, scale_dst, scale_x, upd ? *upd : NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0},
+                     (const double*)nullptr);
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
 }
@@ -495,7 +504,7 @@ int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double
 // kr = kb - J kx with the unscaled matrix; returns ||kr|| (synchronises the stream)
 template <int NF>
 int true_residual(gmpnp_solver* s, double* rn) {
-  hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+  hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
   hipLaunchKernelGGL(k_true_residual, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kb.p, (const double*)s->kt.p,
                      s->kr.p, s->c.part_f, (int)s->ndof);
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -534,7 +543,7 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
       HIP_TRY(hipEventSynchronize(s->ev_dots));
       HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_dots, 0));   // kt is read by k_start_residual below
     } else {
-      hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+      hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
       hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p,
                          s->c.part_f, n, s->n_resblocks);
       HIP_TRY(hipStreamSynchronize(s->stream));
@@ -829,7 +838,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       if (x0_ready && s->stream2 && s->warm_async) {
         HIP_TRY(hipEventRecord(s->ev_jac, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_jac, 0));
-        hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream2, s->c, (const double*)s->kx.p, s->kt.p);
+        hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream2, s->c, (const double*)s->kx.p, s->kt.p);
         hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream2, (const double*)s->kt.p, (const double*)s->kb.p,
                            s->c.part_f, (int)s->ndof, s->n_resblocks);
         HIP_TRY(hipEventRecord(s->ev_dots, s->stream2));
@@ -971,8 +980,25 @@ const char* gmpnp_version(void) { return "gmpnp-mi355x 0.2 (gfx950)"; }
 const char* gmpnp_build_id(void) { return GMPNP_BUILD_ID; }
 const char* gmpnp_last_error(void) { return g_err.c_str(); }
 
+static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                       const gmpnp_options_t* opts, const gmpnp_partition_t* part, gmpnp_solver** out);
+
 int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
                  const gmpnp_options_t* opts, gmpnp_solver** out) {
+  return create_impl(mesh, model, quad, opts, nullptr, out);
+}
+
+int gmpnp_create_partition(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                           const gmpnp_options_t* opts, const gmpnp_partition_t* part, gmpnp_solver** out) {
+  if (!part) return fail(GMPNP_ERR_INVALID, "partition is NULL");
+  if (part->size < 1 || part->rank < 0 || part->rank >= part->size || part->n_neighbours < 0) return fail(GMPNP_ERR_INVALID, "bad partition rank / size");
+  if (part->n_neighbours > 0 && (!part->neighbour_rank || !part->send_ptr || !part->recv_ptr || !part->send_vertices || !part->recv_vertices))
+    return fail(GMPNP_ERR_INVALID, "partition: halo plan missing");
+  return create_impl(mesh, model, quad, opts, part, out);
+}
+
+static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                       const gmpnp_options_t* opts, const gmpnp_partition_t* part, gmpnp_solver** out) {
   if (!mesh || !quad || !out) return fail(GMPNP_ERR_INVALID, "NULL argument");
   *out = nullptr;
   int rc = check_model(model, mesh->dim); if (rc) return rc;
@@ -988,7 +1014,11 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   if (opts) s->opts = *opts;
   if (s->opts.device_id < 0 || s->opts.device_id >= ndev) return fail(GMPNP_ERR_INVALID, "device_id out of range");
   HIP_TRY(hipSetDevice(s->opts.device_id));
-  std::string err = build_topology(*mesh, nf, s->opts.n_aggregates, s->t);
+  if (part) {  // a partitioned handle shares nothing inside a launch and keeps to one stream: the group drives it
+    if (mesh->dim != 3) return fail(GMPNP_ERR_INVALID, "mesh partitions exist for 3D meshes");
+    s->opts.shared_device = 1; s->opts.launch_form = 4;
+  }
+  std::string err = build_topology(*mesh, nf, s->opts.n_aggregates, s->t, part);
   if (!err.empty()) return fail(GMPNP_ERR_INVALID, err);
   Topology& t = s->t;
   s->dim = mesh->dim; s->nf = nf; s->nn = mesh->dim + 1; s->ndof = t.nv * nf; s->nb = (int)t.cols.size();
@@ -1132,6 +1162,35 @@ int gmpnp_create(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, const gmp
   { void* dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, s->h_part, 0)); c.part_f = (double*)dp;
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_status, 0)); c.status_host = (int32_t*)dp; }
   c.scal = s->scal.p; c.status = s->status.p;
+  c.own_node0 = t.own_node0; c.own_node1 = t.own_node1; c.own_agg0 = t.own_agg0; c.own_agg1 = t.own_agg1; c.tile0 = t.own_tile0; c.dist = 0;
+  if (part) {
+    s->partitioned = true; s->part_rank = part->rank; s->part_size = part->size;
+    std::vector<int32_t> sn, rn;
+    s->send_ptr.assign(1, 0); s->recv_ptr.assign(1, 0);
+    for (int q = 0; q < part->n_neighbours; ++q) {
+      if (part->neighbour_rank[q] < 0 || part->neighbour_rank[q] >= part->size || part->neighbour_rank[q] == part->rank)
+        return fail(GMPNP_ERR_INVALID, "partition: bad neighbour rank");
+      s->nb_rank.push_back(part->neighbour_rank[q]);
+      for (int k = part->send_ptr[q]; k < part->send_ptr[q + 1]; ++k) {
+        const int v = part->send_vertices[k];
+        if (v < 0 || v >= nv || !part->vertex_owned[v]) return fail(GMPNP_ERR_INVALID, "partition: send list must name owned local vertices");
+        sn.push_back(t.iperm[v]);
+      }
+      for (int k = part->recv_ptr[q]; k < part->recv_ptr[q + 1]; ++k) {
+        const int v = part->recv_vertices[k];
+        if (v < 0 || v >= nv || part->vertex_owned[v]) return fail(GMPNP_ERR_INVALID, "partition: receive list must name ghost vertices");
+        rn.push_back(t.iperm[v]);
+      }
+      s->send_ptr.push_back((int32_t)sn.size()); s->recv_ptr.push_back((int32_t)rn.size());
+    }
+    HIP_TRY(s->send_nodes.upload(sn)); HIP_TRY(s->recv_nodes.upload(rn));
+    const size_t wmax = (size_t)nf * nf;   // widest exchange: the inverse diagonal blocks of the ghost nodes
+    HIP_TRY(s->sendbuf.alloc(std::max<size_t>(1, sn.size() * wmax))); HIP_TRY(s->recvbuf.alloc(std::max<size_t>(1, rn.size() * wmax)));
+    HIP_TRY(s->red_i.alloc(s->ncoarse)); HIP_TRY(s->red_a.alloc(2 + 3 * (size_t)s->ncoarse)); HIP_TRY(s->red_b.alloc(4 + (size_t)s->ncoarse));
+    HIP_TRY(s->red_norm.alloc(8));
+    HIP_TRY(hipHostMalloc((void**)&s->h_red, 8 * sizeof(double)));
+    c.dist = 1; c.red_i = s->red_i.p; c.red_a = s->red_a.p; c.red_b = s->red_b.p;
+  }
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;
   // the coarse inverse keeps its whole matrix in LDS: opt in to > 64 KiB of dynamic LDS
@@ -1308,7 +1367,7 @@ int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y) {
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
   HIP_TRY(hipSetDevice(s->opts.device_id));
   int rc = upload_vec(s, x, s->kx.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
+  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
                                        (const double*)s->kx.p, s->kt.p));
   HIP_TRY(hipGetLastError());
   return download_vec(s, s->kt.p, y);
@@ -1402,7 +1461,7 @@ int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev) {
   if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
   HIP_TRY(hipSetDevice(s->opts.device_id));
   int rc = import_dev(s, x_dev, s->kx.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
+  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
                                        (const double*)s->kx.p, s->kt.p));
   return export_dev(s, s->kt.p, y_dev);
 }
@@ -1437,21 +1496,21 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
   auto one = [&]() -> int {
     int r = GMPNP_OK;
     switch (kernel) {
-      case 0: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p)); break;
+      case 0: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p)); break;
       case 1: GMPNP_DISPATCH(s, r = (launch_element<DIM, NF>(s, true))); break;
       case 2: GMPNP_DISPATCH(s, r = (launch_jac_gather<DIM, NF>(s))); break;
       case 3: GMPNP_DISPATCH(s, r = (launch_res_gather<DIM, NF>(s))); break;
-      case 4: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
-      case 5: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 4: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 5: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
       case 6: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_a<NF>), dim3(std::max(1, s->t.nagg)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
       case 7: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_coarse_b<NF>), dim3(std::max(1, s->t.nagg)), dim3(kCoarseThreads), 0, s->stream, s->c, 1)); break;
       case 8: hipLaunchKernelGGL(k_copy2, dim3(1), dim3(64), 0, s->stream, s->yc.p, (double*)nullptr, s->cpart_t.p, 64); break;
       case 9: hipLaunchKernelGGL(k_stream_read, dim3(2048), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 10: hipLaunchKernelGGL(k_stream_read, dim3(512), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
       case 11: hipLaunchKernelGGL(k_stream_read, dim3(8192), dim3(256), 0, s->stream, (const double2*)s->vals_s.p, s->vals_s.n / 2, s->part_f.p); break;
-      case 12: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_a<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
+      case 12: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_a<NF>), dim3(s->t.nagg + s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
                                                     (unsigned)(++s->fused_seq))); break;
-      case 13: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_b<NF>), dim3(s->t.nagg + s->t.ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
+      case 13: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_b<NF>), dim3(s->t.nagg + s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
                                                     (unsigned)(++s->fused_seq))); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
@@ -1547,3 +1606,5 @@ int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int
 }
 
 }  // extern "C"
+
+#include "gmpnp_group.h"

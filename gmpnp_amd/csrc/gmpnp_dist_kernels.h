@@ -1,0 +1,86 @@
+// Kernels of the mesh-partitioned solve (one handle per rank): packing of the ghost rows that travel after
+// each BiCGStab half-iteration, the per-rank sums that travel in the one all-reduce of a half-iteration, and the device side
+// of the in-process rehearsal transport.  The tile and coarse kernels themselves are those of the single-GPU solver
+// (gmpnp_kernels.h): they run the owned tiles only (Ctx::tile0) and, with Ctx::dist, read all-reduced sums.
+#pragma once
+#include "gmpnp_kernels.h"
+
+namespace gmpnp {
+
+struct VecList { const double* p[4]; };
+struct VecListW { double* p[4]; };
+
+// buf[((k * nvec) + v) * width + f] = src_v[nodes[k] * width + f]: node-major, so the rows for one neighbour (a contiguous
+// range of k) are one contiguous message whatever the number of vectors.
+__global__ __launch_bounds__(256) void k_halo_pack(const VecList src, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                    double* __restrict__ buf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes * nvec * width) return;
+  const int f = i % width, v = (i / width) % nvec, k = i / (width * nvec);
+  buf[i] = src.p[v][(size_t)nodes[k] * width + f];
+}
+__global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                      const double* __restrict__ buf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes * nvec * width) return;
+  const int f = i % width, v = (i / width) % nvec, k = i / (width * nvec);
+  dst.p[v][(size_t)nodes[k] * width + f] = buf[i];
+}
+
+// One wave per output value: a fixed-order sum of per-tile scalar partials or of per-slot restriction partials.
+//   phase 0 (start of a solve)  out[d]                = sum_slot cpart_v[1][slot][d]                 (P^T r_0, left by k_krylov_init)
+//   phase 1 (after half A)      out[0..1]             = sum_tile part_a, part_rr ; out[2 + w n + d] = sum_slot (v, r, p)[par]
+//   phase 2 (after half B)      out[0..3]             = sum_tile part_b[m]       ; out[4 + d]       = sum_slot cpart_t
+//   phase 3 (end of a solve)    out[d]                = sum_slot cpart_v[0][slot][d]                 (P^T y, left by k_restrict)
+__global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int par, double* __restrict__ out) {
+  const int n = c.ncoarse, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int nscal = phase == 1 ? 2 : (phase == 2 ? 4 : 0);
+  const int nvecs = phase == 1 ? 3 : 1;
+  if (wave >= nscal + nvecs * n) return;
+  double acc = 0.0;
+  if (wave < nscal) {
+    const double* p = phase == 1 ? (wave == 0 ? c.part_a : c.part_rr) : c.part_b + (size_t)wave * c.ntiles;
+    for (int i = lane; i < c.ntiles; i += 64) acc += p[i];
+  } else {
+    const int q = wave - nscal, w = q / n, d = q - w * n;
+    const double* p = phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
+                      : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par]);
+    for (int sl = lane; sl < c.tile_slots; sl += 64) acc += p[(size_t)sl * n + d];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[wave] = acc;
+}
+
+// ||b||^2 of the owned rows (k_res_gather's per-workgroup partials) and the four status bits, as doubles for the all-reduce
+__global__ __launch_bounds__(256) void k_norm_reduce(const double* __restrict__ part, int nblocks, const int32_t* __restrict__ status,
+                                                      double* __restrict__ out) {
+  __shared__ double lds[4];
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < nblocks; i += 256) v[0] += part[i];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) {
+    out[0] = v[0];
+    const int st = *status;
+    for (int b = 0; b < 4; ++b) out[1 + b] = (st >> b) & 1 ? 1.0 : 0.0;
+  }
+}
+
+// Galerkin matrix before its all-reduce: rows of aggregates this rank does not own come from ghost (identity) rows
+__global__ __launch_bounds__(256) void k_zero_foreign_rows(double* __restrict__ Ac, int n, int row0, int row1) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n * n) return;
+  const int r = q / n;
+  if (r < row0 || r >= row1) Ac[q] = 0.0;
+}
+
+// In-process rehearsal transport: sum over the handles of one process, written back to all of them (fixed order)
+struct PtrList { double* p[8]; };
+__global__ __launch_bounds__(256) void k_local_allreduce(const PtrList bufs, int nb, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += bufs.p[b][i];
+  for (int b = 0; b < nb; ++b) bufs.p[b][i] = s;
+}
+
+}  // namespace gmpnp

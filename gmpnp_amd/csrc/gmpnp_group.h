@@ -1,0 +1,437 @@
+// Mesh-partitioned Newton solve inside the library (include/gmpnp.h, "mesh-partitioned solve").
+// Included at the end of gmpnp_api.hip: uses the handle type and the launch helpers defined there.
+//
+// One handle per rank on the rank's local mesh (owned + one ghost layer).  Per BiCGStab half-iteration and rank:
+//     coarse kernel (scalars + coarse solve from all-reduced sums)  ->  tile kernel on the owned tiles (SpMV + vector updates)
+//     ->  k_dist_reduce (per-rank sums)  ->  ONE all-reduce  +  ONE grouped send/recv of the ghost rows  ->  k_halo_unpack
+// Nothing of the loop runs on the host except the launches; the host reads the device's verdict once per burst, and every
+// rank launches the same bursts (the burst schedule depends only on all-reduced quantities), so the collectives pair up.
+//
+// Transports: RCCL (one process per GPU; ncclAllReduce / grouped ncclSend+ncclRecv on the solver's stream, librccl.so loaded
+// with dlopen on first use) or, for a group that holds ALL ranks of the partition in one process, device copies between the
+// handles on one shared stream (rehearsal of the whole algorithm on a single GPU).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl_api(std::string* why) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) err = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
+    else {
+      auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p && err.empty()) err = std::string("librccl.so lacks ") + n; return p; };
+      api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+      api.Send = (decltype(api.Send))sym("ncclSend");
+      api.Recv = (decltype(api.Recv))sym("ncclRecv");
+      api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+      api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    }
+  }
+  if (!err.empty()) { if (why) *why = err; return nullptr; }
+  return &api;
+}
+
+#define NCCL_TRY(api, expr)                                                                        \
+  do {                                                                                             \
+    ncclResult_t r__ = (expr);                                                                     \
+    if (r__ != ncclSuccess)                                                                        \
+      return fail(GMPNP_ERR_HIP, std::string(#expr) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(r__) : "RCCL error")); \
+  } while (0)
+
+}  // namespace
+
+struct gmpnp_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, size = 1, device = 0;
+};
+
+struct gmpnp_group {
+  std::vector<gmpnp_solver*> dom;       // local handles, ascending rank
+  gmpnp_comm* comm = nullptr;           // RCCL transport (exactly one local handle) or nullptr (all ranks in this process)
+  std::vector<hipStream_t> own_stream;  // in-process mode: the handles' own streams, given back at destroy
+  std::vector<std::vector<int>> peer_slot;  // in-process mode: peer_slot[d][j] = index of d in the neighbour list of d's neighbour j
+  int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
+};
+
+namespace {
+
+// ---- collectives over the local handles ------------------------------------------------------------------------------------
+template <class F>
+int group_allreduce(gmpnp_group* g, F buf_of, int n) {
+  if (g->comm) {
+    RcclApi* api = rccl_api(nullptr);
+    gmpnp_solver* s = g->dom[0];
+    NCCL_TRY(api, api->AllReduce(buf_of(s), buf_of(s), (size_t)n, ncclDouble, ncclSum, g->comm->comm, s->stream));
+    return GMPNP_OK;
+  }
+  PtrList pl{};
+  for (size_t d = 0; d < g->dom.size(); ++d) pl.p[d] = buf_of(g->dom[d]);
+  hipLaunchKernelGGL(k_local_allreduce, dim3(grid_for(n, 256)), dim3(256), 0, g->dom[0]->stream, pl, (int)g->dom.size(), n);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+// Ghost rows of up to four nodal arrays (`width` doubles per node) from their owners: pack, one message per neighbour, unpack.
+template <class F>
+int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
+  for (gmpnp_solver* s : g->dom) {
+    const int nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+    if (nsn == 0) continue;
+    VecListW w = vecs_of(s); VecList src{};
+    for (int v = 0; v < 4; ++v) src.p[v] = w.p[v];
+    hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(nsn * nvec * width, 256)), dim3(256), 0, s->stream, src, nvec, width,
+                       (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p);
+  }
+  HIP_TRY(hipGetLastError());
+  const size_t per = (size_t)nvec * width;
+  if (g->comm) {
+    RcclApi* api = rccl_api(nullptr);
+    gmpnp_solver* s = g->dom[0];
+    if (!s->nb_rank.empty()) {
+      NCCL_TRY(api, api->GroupStart());
+      for (size_t j = 0; j < s->nb_rank.size(); ++j) {
+        const size_t ns = (size_t)(s->send_ptr[j + 1] - s->send_ptr[j]) * per, nr = (size_t)(s->recv_ptr[j + 1] - s->recv_ptr[j]) * per;
+        if (ns) NCCL_TRY(api, api->Send(s->sendbuf.p + (size_t)s->send_ptr[j] * per, ns, ncclDouble, s->nb_rank[j], g->comm->comm, s->stream));
+        if (nr) NCCL_TRY(api, api->Recv(s->recvbuf.p + (size_t)s->recv_ptr[j] * per, nr, ncclDouble, s->nb_rank[j], g->comm->comm, s->stream));
+      }
+      NCCL_TRY(api, api->GroupEnd());
+    }
+  } else {
+    for (size_t d = 0; d < g->dom.size(); ++d) {
+      gmpnp_solver* s = g->dom[d];
+      for (size_t j = 0; j < s->nb_rank.size(); ++j) {
+        gmpnp_solver* q = g->dom[s->nb_rank[j]];
+        const int jj = g->peer_slot[d][j];
+        const size_t ns = (size_t)(s->send_ptr[j + 1] - s->send_ptr[j]) * per;
+        if (ns) HIP_TRY(hipMemcpyAsync(q->recvbuf.p + (size_t)q->recv_ptr[jj] * per, s->sendbuf.p + (size_t)s->send_ptr[j] * per,
+                                       ns * sizeof(double), hipMemcpyDeviceToDevice, g->dom[0]->stream));
+      }
+    }
+  }
+  for (gmpnp_solver* s : g->dom) {
+    const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back();
+    if (nrn == 0) continue;
+    hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(nrn * nvec * width, 256)), dim3(256), 0, s->stream, vecs_of(s), nvec, width,
+                       (const int32_t*)s->recv_nodes.p, nrn, (const double*)s->recvbuf.p);
+  }
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+// ---- residual: ||b||_2 over all ranks' owned rows and the OR of the status bits -----------------------------------------------
+template <int DIM, int NF>
+int group_residual(gmpnp_group* g, double* norm, int* flags) {
+  for (gmpnp_solver* s : g->dom) {
+    int rc = launch_element<DIM, NF>(s, true); if (rc) return rc;
+    rc = launch_res_gather<DIM, NF>(s); if (rc) return rc;
+    hipLaunchKernelGGL(k_norm_reduce, dim3(1), dim3(256), 0, s->stream, (const double*)s->c.part_f, s->n_resblocks,
+                       (const int32_t*)s->status.p, s->red_norm.p);
+  }
+  int rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_norm.p; }, 5); if (rc) return rc;
+  gmpnp_solver* s0 = g->dom[0];
+  HIP_TRY(hipMemcpyAsync(s0->h_red, s0->red_norm.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
+  HIP_TRY(hipStreamSynchronize(s0->stream));
+  *norm = std::sqrt(s0->h_red[0]);
+  int f = 0;
+  for (int b = 0; b < 4; ++b) if (s0->h_red[1 + b] > 0.0) f |= 1 << b;
+  *flags = f;
+  return GMPNP_OK;
+}
+
+// ---- preconditioner of the partitioned operator: node-block Jacobi (ghost blocks from their owners) + GLOBAL slab coarse space ----
+template <int NF>
+int group_setup(gmpnp_group* g, int mode) {
+  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  for (gmpnp_solver* s : g->dom) {
+    s->c.use_coarse = use_coarse;
+    hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 4)), dim3(64), 0, s->stream, s->c);
+  }
+  // As = J Dinv needs the owners' inverse blocks at the ghost COLUMNS (the local ghost rows are identity rows)
+  int rc = group_exchange(g, NF * NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->Dinv.p; return w; }); if (rc) return rc;
+  for (gmpnp_solver* s : g->dom)
+    hipLaunchKernelGGL((k_scale_columns<NF>), dim3(grid_for(s->c.n_work * kWave, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
+  if (use_coarse) {
+    for (gmpnp_solver* s : g->dom) {
+      const int n = s->ncoarse;
+      hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
+      hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, s->stream, s->c);
+      hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
+      hipLaunchKernelGGL(k_zero_foreign_rows, dim3(grid_for(n * n, 256)), dim3(256), 0, s->stream, s->Ac.p, n, s->t.own_agg0 * NF, s->t.own_agg1 * NF);
+    }
+    const int n = g->dom[0]->ncoarse;
+    rc = group_allreduce(g, [](gmpnp_solver* s) { return s->Ac.p; }, n * n); if (rc) return rc;   // ONE all-reduce per set-up
+    for (gmpnp_solver* s : g->dom)
+      hipLaunchKernelGGL((k_coarse_invert<NF>), dim3(1), dim3(512), coarse_lds_bytes(n, NF), s->stream, s->c);
+  }
+  HIP_TRY(hipGetLastError());
+  for (gmpnp_solver* s : g->dom) { s->precond_valid = true; s->precond_mode = mode; }
+  return GMPNP_OK;
+}
+
+// ---- BiCGStab across the ranks: rhs in kr (owned rows; k_res_gather left it there), ||rhs|| = bnorm (global); leaves y in ky ----
+template <int NF>
+int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st) {
+  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  const int n = g->dom[0]->ncoarse;
+  KrylovScalars init{};
+  init.rho[0] = init.rho[1] = bnorm * bnorm; init.alpha = 1.0;
+  init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.max_iters = maxit; init.rr0 = bnorm * bnorm;
+  if (!(bnorm > 0.0)) init.done = 1;
+  for (gmpnp_solver* s : g->dom) {
+    s->c.use_coarse = use_coarse;
+    hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, (const double*)nullptr, init, s->cpart_v1.p);
+    if (use_coarse) hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for(n * kWave, 256)), dim3(256), 0, s->stream, s->c, 0, 0, s->red_i.p);
+  }
+  HIP_TRY(hipGetLastError());
+  int rc;
+  if (use_coarse) { rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_i.p; }, n); if (rc) return rc; }
+  rc = group_exchange(g, NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kr.p; return w; }); if (rc) return rc;   // p_0 = r_0 at the ghost columns
+  const dim3 cg(std::max(1, g->dom[0]->t.nagg));
+  KrylovScalars res = init;
+  int k = 0;
+  auto iteration = [&]() -> int {
+    const int par = k & 1;
+    for (gmpnp_solver* s : g->dom) {
+      hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for((2 + 3 * n) * kWave, 256)), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p);
+    }
+    int r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_a.p; }, 2 + 3 * n); if (r) return r;
+    r = group_exchange(g, NF, 3, [par](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kr.p; w.p[1] = s->c.kv[par]; w.p[2] = s->c.kp[par]; return w; });
+    if (r) return r;
+    for (gmpnp_solver* s : g->dom) {
+      hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for((4 + n) * kWave, 256)), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p);
+    }
+    r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_b.p; }, 4 + n); if (r) return r;
+    r = group_exchange(g, NF, 2, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->ks.p; w.p[1] = s->kt.p; return w; });
+    if (r) return r;
+    ++k;
+    HIP_TRY(hipGetLastError());
+    return GMPNP_OK;
+  };
+  if (!res.done) {
+    // Bursts: every rank launches the SAME number of iterations (the schedule depends only on the previous solve's count and
+    // on `done`, both identical on all ranks), then reads the device's verdict.  Iterations launched behind the end of the
+    // solve exit at their first instruction; their collectives still pair up.
+    int burst = std::max(2, (7 * g->last_iters) / 8);
+    gmpnp_solver* s0 = g->dom[0];
+    while (true) {
+      for (int it = 0; it < burst; ++it) { rc = iteration(); if (rc) return rc; }
+      HIP_TRY(hipMemcpyAsync(&s0->h_scal[0], s0->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s0->stream));
+      for (gmpnp_solver* s : g->dom) HIP_TRY(hipStreamSynchronize(s->stream));
+      res = s0->h_scal[0];
+      if (res.done) break;
+      if (k > maxit + 8) break;
+      burst = 4;
+    }
+  }
+  g->last_iters = res.iters;
+  for (gmpnp_solver* s : g->dom) s->last_done = res.done;
+  if (st) { st->iterations = res.iters; st->converged = (res.done == 1); st->residual_norm = std::sqrt(res.rr); st->rhs_norm = bnorm; }
+  if (res.done != 1) {
+    char buf[200];
+    snprintf(buf, sizeof buf, "partitioned BiCGStab stopped without convergence (code %d) after %d iterations, ||r|| = %.3e, ||b|| = %.3e",
+             res.done, res.iters, std::sqrt(res.rr), bnorm);
+    return fail(GMPNP_ERR_LINEAR, buf);
+  }
+  return GMPNP_OK;
+}
+
+// x = Dinv (I + P Aci P^T) y on the owned rows, ghost rows from their owners, then u -= omega x on every local row
+template <int NF>
+int group_update(gmpnp_group* g, int mode, double omega) {
+  const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  const int n = g->dom[0]->ncoarse;
+  if (use_coarse) {
+    for (gmpnp_solver* s : g->dom) {
+      hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, (const double*)s->ky.p, s->cpart_v0.p);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for(n * kWave, 256)), dim3(256), 0, s->stream, s->c, 3, 0, s->red_i.p);
+    }
+    int rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_i.p; }, n); if (rc) return rc;
+  }
+  for (gmpnp_solver* s : g->dom)
+    hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->ky.p,
+                       (const double*)s->cpart_v0.p, s->kx.p, 0.0, 1.0, NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0}, (const double*)s->red_i.p);
+  int rc = group_exchange(g, NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kx.p; return w; }); if (rc) return rc;
+  for (gmpnp_solver* s : g->dom)
+    hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p, -omega, (int)s->ndof);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
+template <int DIM, int NF>
+int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_stats_t& st) {
+  const double t0 = now_ms();
+  for (gmpnp_solver* s : g->dom) HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+  // ghost values of u and u_n are the owners' values from here on (the caller's scatter normally made them so already)
+  int rc = group_exchange(g, NF, 2, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->u.p; w.p[1] = s->un.p; return w; }); if (rc) return rc;
+  double r = 0.0; int flags = 0;
+  rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
+  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual is NaN before the first Newton iteration");
+  const double r0 = r;
+  st.residuals[0] = r; st.n_residuals = 1;
+  auto conv = [&](double res) { const double rel = res / r0; return rel < o.relative_tolerance || res < o.absolute_tolerance; };
+  bool done = conv(r);
+  while (!done && st.iterations < o.maximum_iterations) {
+    for (gmpnp_solver* s : g->dom) { rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc; s->jacobian_valid = true; }
+    rc = group_setup<NF>(g, o.linear_solver); if (rc) return rc;
+    gmpnp_linear_stats_t ls{};
+    rc = group_krylov<NF>(g, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, o.krylov_maximum_iterations, &ls);
+    if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
+    st.krylov_iterations += ls.iterations;
+    if (rc) return rc;
+    rc = group_update<NF>(g, o.linear_solver, o.relaxation_parameter); if (rc) return rc;
+    st.iterations++;
+    rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
+    if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+    if (flags & 14) return fail(GMPNP_ERR_LINEAR, status_message(flags));
+    if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
+    if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
+    done = conv(r);
+  }
+  for (gmpnp_solver* s : g->dom) { s->state_jumped = false; s->x0_predicted = false; }
+  st.converged = done ? 1 : 0;
+  st.ms_total = now_ms() - t0;
+  if (!done) return fail(GMPNP_ERR_NOT_CONVERGED, "Newton solver did not converge because maximum number of iterations reached");
+  return GMPNP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmpnp_comm_unique_id(char id[GMPNP_COMM_ID_BYTES]) {
+  static_assert(GMPNP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (!id) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(GMPNP_ERR_HIP, why);
+  ncclUniqueId u;
+  NCCL_TRY(api, api->GetUniqueId(&u));
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return GMPNP_OK;
+}
+
+int gmpnp_comm_create(const char id[GMPNP_COMM_ID_BYTES], int32_t rank, int32_t size, int32_t device_id, gmpnp_comm** out) {
+  if (!id || !out || size < 1 || rank < 0 || rank >= size) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(GMPNP_ERR_HIP, why);
+  HIP_TRY(hipSetDevice(device_id));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  std::unique_ptr<gmpnp_comm> c(new gmpnp_comm);
+  c->rank = rank; c->size = size; c->device = device_id;
+  NCCL_TRY(api, api->CommInitRank(&c->comm, size, u, rank));
+  *out = c.release();
+  return GMPNP_OK;
+}
+
+void gmpnp_comm_destroy(gmpnp_comm* c) {
+  if (!c) return;
+  RcclApi* api = rccl_api(nullptr);
+  if (api && c->comm) { (void)hipSetDevice(c->device); (void)api->CommDestroy(c->comm); }
+  delete c;
+}
+
+int gmpnp_group_create(int32_t n_local, gmpnp_solver* const* handles, gmpnp_comm* comm, gmpnp_group** out) {
+  if (n_local < 1 || !handles || !out) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  std::unique_ptr<gmpnp_group> g(new gmpnp_group);
+  for (int d = 0; d < n_local; ++d) {
+    gmpnp_solver* s = handles[d];
+    if (!s || !s->partitioned) return fail(GMPNP_ERR_INVALID, "group members must come from gmpnp_create_partition");
+    g->dom.push_back(s);
+  }
+  gmpnp_solver* s0 = g->dom[0];
+  for (gmpnp_solver* s : g->dom)
+    if (s->part_size != s0->part_size || s->ncoarse != s0->ncoarse || s->nf != s0->nf || s->opts.device_id != s0->opts.device_id)
+      return fail(GMPNP_ERR_INVALID, "group members disagree on partition size, coarse space, fields or device");
+  if (comm) {
+    if (n_local != 1) return fail(GMPNP_ERR_INVALID, "with a communicator a process drives exactly one partition handle");
+    if (comm->size != s0->part_size || comm->rank != s0->part_rank) return fail(GMPNP_ERR_INVALID, "communicator rank/size differ from the partition's");
+    g->comm = comm;
+  } else {
+    if (n_local != s0->part_size || n_local > 8) return fail(GMPNP_ERR_INVALID, "without a communicator the group must hold every rank of the partition (at most 8)");
+    for (int d = 0; d < n_local; ++d) if (g->dom[d]->part_rank != d) return fail(GMPNP_ERR_INVALID, "handles must be given in rank order");
+    g->peer_slot.resize(n_local);
+    for (int d = 0; d < n_local; ++d) {
+      gmpnp_solver* s = g->dom[d];
+      for (size_t j = 0; j < s->nb_rank.size(); ++j) {
+        gmpnp_solver* q = g->dom[s->nb_rank[j]];
+        int jj = -1;
+        for (size_t z = 0; z < q->nb_rank.size(); ++z) if (q->nb_rank[z] == d) jj = (int)z;
+        if (jj < 0 || (q->recv_ptr[jj + 1] - q->recv_ptr[jj]) != (s->send_ptr[j + 1] - s->send_ptr[j]))
+          return fail(GMPNP_ERR_INVALID, "halo plans of two neighbouring ranks do not match");
+        g->peer_slot[d].push_back(jj);
+      }
+    }
+    // one stream for all handles of the process: their launches and the copies between them are ordered without events
+    HIP_TRY(hipSetDevice(s0->opts.device_id));
+    g->own_stream.resize(n_local, nullptr);
+    for (int d = 1; d < n_local; ++d) {
+      HIP_TRY(hipStreamSynchronize(g->dom[d]->stream));
+      g->own_stream[d] = g->dom[d]->stream; g->dom[d]->stream = s0->stream;
+    }
+  }
+  *out = g.release();
+  return GMPNP_OK;
+}
+
+void gmpnp_group_destroy(gmpnp_group* g) {
+  if (!g) return;
+  if (!g->dom.empty()) { (void)hipSetDevice(g->dom[0]->opts.device_id); (void)hipStreamSynchronize(g->dom[0]->stream); }
+  for (size_t d = 1; d < g->own_stream.size(); ++d) if (g->own_stream[d]) g->dom[d]->stream = g->own_stream[d];
+  delete g;
+}
+
+int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* o, gmpnp_newton_stats_t* stats) {
+  if (!g || !o) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (o->maximum_iterations < 0 || o->krylov_maximum_iterations < 1) return fail(GMPNP_ERR_INVALID, "bad iteration limits");
+  if (o->linear_solver != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && o->linear_solver != GMPNP_LINEAR_BICGSTAB_JACOBI)
+    return fail(GMPNP_ERR_INVALID, "the partitioned solve uses BiCGStab (two-level or Jacobi)");
+  gmpnp_newton_stats_t local{};
+  gmpnp_newton_stats_t& st = stats ? *stats : local;
+  st = gmpnp_newton_stats_t{};
+  HIP_TRY(hipSetDevice(g->dom[0]->opts.device_id));
+  return group_newton<3, 9>(g, *o, st);
+}
+
+int gmpnp_group_assign_previous(gmpnp_group* g) {
+  if (!g) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(g->dom[0]->opts.device_id));
+  for (gmpnp_solver* s : g->dom) HIP_TRY(hipMemcpyAsync(s->un.p, s->u.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+  return GMPNP_OK;
+}
+
+}  // extern "C"

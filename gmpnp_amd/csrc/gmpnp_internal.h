@@ -163,6 +163,14 @@ struct Ctx {
   uint32_t* ticket; // fused launch form: coarse workgroups finished so far in this solve
   HostPoll* poll;   // host-visible progress of the solve (pinned memory, device pointer)
   int32_t* status_host;  // pinned copy of *status, refreshed by k_res_gather (the host reads it with the residual norm)
+  // partitioned solve (one handle per rank): owned ranges and the buffers of the fused exchanges
+  int32_t own_node0, own_node1;   // owned nodes (internal order); [0, nv) for an unpartitioned handle
+  int32_t own_agg0, own_agg1;     // aggregates made of owned nodes
+  int32_t tile0;                  // first owned tile: the Krylov workgroups run tiles tile0 + blockIdx.x
+  int32_t dist;                   // 1 = partitioned: the coarse kernels read all-reduced sums from `red` instead of tile partials
+  double* red_i;                  // [ncoarse]          P^T r_0                                  (all-reduced over the ranks)
+  double* red_a;                  // [2 + 3 ncoarse]    (rhat,v) ||r||^2 | P^T v | P^T r | P^T p
+  double* red_b;                  // [4 + ncoarse]      (t,s) (t,t) (rhat,s) (rhat,t) | P^T t
   const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722
   int32_t supg_w[GMPNP_MAX_SPECIES];  // species whose gradient enters species i's strong residual (identity except Q7)
 };
@@ -187,6 +195,9 @@ struct Topology {
   std::vector<TileRec> tile_rec;
   int col_stride = 0;
   int ntiles = 0, tile_slots = 0;
+  int own_node0 = 0, own_node1 = 0;       // internal node range this handle owns (partitioned solve; everything otherwise)
+  int own_agg0 = 0, own_agg1 = 0;         // aggregates made of owned nodes
+  int own_tile0 = 0, own_ntiles = 0;      // their tiles (contiguous)
   std::vector<int32_t> lu_node, lu_pos;   // elimination order of the block-banded LU: lu_node[position] = internal node
   int lu_band = 0;                        // max |lu_pos[I] - lu_pos[J]| over the blocks of the pattern
 };
@@ -202,6 +213,7 @@ struct BandLU {
 };
 
 // Builds every table above; returns an error message or "" on success.
-std::string build_topology(const gmpnp_mesh_t& mesh, int nf, int n_aggregates_requested, Topology& t);
+std::string build_topology(const gmpnp_mesh_t& mesh, int nf, int n_aggregates_requested, Topology& t,
+                           const gmpnp_partition_t* part = nullptr);
 
 }  // namespace gmpnp

@@ -438,7 +438,10 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
   const int r = blockIdx.x * kVecBlock + threadIdx.x;
   double val = 0.0;
   if (r < c.ndof) {
-    if (c.bcflag[r]) {
+    const int Ig = r / NF;
+    if (Ig < c.own_node0 || Ig >= c.own_node1) {
+      val = 0.0;   // ghost row of a partitioned handle: the owner's rank holds it
+    } else if (c.bcflag[r]) {
       val = c.u[r] - c.bcval[r];
     } else {
       const int I = r / NF, i = r - I * NF;
@@ -1140,13 +1143,21 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   else { alpha = sc_alpha; rho_old = par ? sc_rho0 : sc_rho1; }
   GMPNP_STAMP(1);
   // ONE barrier: restriction sums of this aggregate and per-wave scalar sums go to LDS, then every thread finishes alone
-  if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
-  if (!first) psum.reduce_partial(lred, c.part_b, c.ntiles, c.ntiles);
+  if (c.dist) {  // partitioned solve: the sums over all ranks' tiles were all-reduced into red_i / red_a / red_b
+    if (c.use_coarse && t < 4 * NF) {
+      const int which = t / NF, f = t - which * NF, d = g * NF + f;
+      cs[t] = first ? c.red_i[d] : (which == 0 ? c.red_a[2 + d] : which == 1 ? c.red_b[4 + d] : which == 2 ? c.red_a[2 + n + d] : c.red_a[2 + 2 * n + d]);
+    }
+  } else {
+    if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
+    if (!first) psum.reduce_partial(lred, c.part_b, c.ntiles, c.ntiles);
+  }
   __syncthreads();
   GMPNP_STAMP(2);
   if (!first) {
     double tot[4];
-    PartialSums<4>::reduce_final(lred, tot);
+    if (c.dist) { tot[0] = c.red_b[0]; tot[1] = c.red_b[1]; tot[2] = c.red_b[2]; tot[3] = c.red_b[3]; }
+    else PartialSums<4>::reduce_final(lred, tot);
     omega = tot[0] / tot[1];
     rho_new = tot[2] - omega * tot[3];
     beta = (rho_new / rho_old) * (alpha / omega);
@@ -1193,11 +1204,16 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
 #pragma unroll
     for (int f = 0; f < NF; ++f) keep += acol[f];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
-  if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
-  psum.reduce_partial(lred, c.part_a, c.ntiles, c.ntiles);
+  if (c.dist) {
+    if (c.use_coarse && t < 2 * NF) { const int which = t / NF, f = t - which * NF; cs[t] = c.red_a[2 + which * n + g * NF + f]; }
+  } else {
+    if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
+    psum.reduce_partial(lred, c.part_a, c.ntiles, c.ntiles);
+  }
   __syncthreads();
   double tot[2];
-  PartialSums<2>::reduce_final(lred, tot);
+  if (c.dist) { tot[0] = c.red_a[0]; tot[1] = c.red_a[1]; }
+  else PartialSums<2>::reduce_final(lred, tot);
   const double rv = tot[0], rr = tot[1];
   int done = 0;
   if (!(rr == rr) || !(rv == rv)) done = 3;
@@ -1405,7 +1421,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     if (!dn) tcs.template load_values<true>(c);
   }
   if (dn) {
-    if (tile == 0 && t == 0) {
+    if (tile == c.tile0 && t == 0) {
       sc->done = dn;  // published here: no workgroup of THIS launch reads it any more... others exit on dn
       poll_finish(c, FUSED ? load_coherent(&sc->rr) : sc->rr, k, dn);  // the verdict of coarse_b(k) is on r_k: k iterations done
     }
@@ -1454,7 +1470,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
       for (int q = 0; q < kSlicesPerTile; ++q) a0 += dpart[q][m];
       c.part_b[(size_t)m * c.ntiles + tile] = a0;
     }
-    if (tile == 0) { sc->iters = k + 1; poll_store(&c.poll->iters, k + 1); }
+    if (tile == c.tile0) { sc->iters = k + 1; poll_store(&c.poll->iters, k + 1); }
   }
 }
 
@@ -1465,9 +1481,9 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const 
 template <int NF>
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) { coarse_b_body<NF, false>(c, k, blockIdx.x, 0u); }
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
 
 // ... or two: the nagg coarse workgroups ride in front of the tile workgroups of the same launch.  A tile workgroup
 // requests everything that does not depend on the coarse result (indices, matrix slice, operand vectors), then waits
@@ -1478,12 +1494,12 @@ static_assert(kCoarseThreads == kKrylovThreads, "coarse and tile workgroups shar
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_a(const Ctx c, const int k, const unsigned target) {
   if ((int)blockIdx.x < c.nagg) coarse_a_body<NF, true>(c, k, blockIdx.x, target);
-  else bicg_a_body<NF, true>(c, k, blockIdx.x - c.nagg, target);
+  else bicg_a_body<NF, true>(c, k, c.tile0 + blockIdx.x - c.nagg, target);
 }
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b(const Ctx c, const int k, const unsigned target) {
   if ((int)blockIdx.x < c.nagg) coarse_b_body<NF, true>(c, k, blockIdx.x, target);
-  else bicg_b_body<NF, true>(c, k, blockIdx.x - c.nagg, target);
+  else bicg_b_body<NF, true>(c, k, c.tile0 + blockIdx.x - c.nagg, target);
 }
 
 // Plain y = A x with the UNSCALED matrix (parity hook, partitioned driver); same tiling as the Krylov kernels.
@@ -1492,7 +1508,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, cons
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double xs[kTileCols * NF];
-  const int tile = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const int tile = c.tile0 + blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;   // owned tiles only
   const int sl = wv / NW;
   const TileRec rec = c.tile_rec[tile];
   const int c0 = tile * c.col_stride;
@@ -1541,7 +1557,7 @@ __global__ __launch_bounds__(kVecBlock) void k_scale_columns(const Ctx c) {
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_restrict(const Ctx c, const double* __restrict__ x, double* __restrict__ part) {
   __shared__ double lv[kSlicesPerTile * 64];
-  const int tile = blockIdx.x, t = threadIdx.x;
+  const int tile = c.tile0 + blockIdx.x, t = threadIdx.x;
   if (t < kSlicesPerTile * 64) {
     const int sl = t >> 6, lane = t & 63, s = c.tile_slice0[tile] + sl;
     const int Iloc = lane / NF, i = lane - Iloc * NF;
@@ -1564,14 +1580,16 @@ struct NewtonUpdate { double* u; double* xp; double omega, a, b; };
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, const double* __restrict__ x, const double* __restrict__ part,
                                                                 double* __restrict__ dst, double scale_dst, double scale_x,
-                                                                const NewtonUpdate upd) {
+                                                                const NewtonUpdate upd, const double* __restrict__ reduced) {
   __shared__ double pcs[kMaxCoarse];
   __shared__ double ycl[kTileAggs * NF];
   __shared__ double xv[kSlicesPerTile][64];
-  const int tile = blockIdx.x, t = threadIdx.x;
+  const int tile = c.tile0 + blockIdx.x, t = threadIdx.x;
   int own_slot = 0;
   if (c.use_coarse) {
-    if (t < c.ncoarse) {  // fixed-order sum over the slots, eight requests in flight at a time
+    if (reduced) {  // partitioned solve: P^T x summed over the ranks already
+      if (t < c.ncoarse) pcs[t] = reduced[t];
+    } else if (t < c.ncoarse) {  // fixed-order sum over the slots, eight requests in flight at a time
       double sacc = 0.0;
       for (int q0 = 0; q0 < c.tile_slots; q0 += 8) {
         double w[8];
@@ -1696,7 +1714,7 @@ template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_krylov_init(const Ctx c, const double* __restrict__ shadow, const KrylovScalars init,
                                                            double* __restrict__ part) {
   __shared__ double lv[kSlicesPerTile * 64];
-  const int tile = blockIdx.x, t = threadIdx.x;
+  const int tile = c.tile0 + blockIdx.x, t = threadIdx.x;
   if (t < kSlicesPerTile * 64) {
     const int sl = t >> 6, lane = t & 63, s = c.tile_slice0[tile] + sl;
     const int Iloc = lane / NF, i = lane - Iloc * NF;
@@ -1710,7 +1728,7 @@ __global__ __launch_bounds__(kVecBlock) void k_krylov_init(const Ctx c, const do
     }
     lv[t] = v;
   }
-  if (tile == 0) {
+  if (blockIdx.x == 0) {
     for (int q = t; q < 16 * 66; q += kVecBlock) c.ticket[q] = 0u;
     if (t == 0) *c.scal = init;
   }

@@ -10,14 +10,15 @@
 
 namespace gmpnp {
 
-static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t);
+static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t,
+                              const gmpnp_partition_t* part);
 
 // Two passes: the first (caller's order) fixes the aggregate count and the node degrees; nodes are then stably
 // re-sorted by decreasing degree INSIDE each aggregate (equal-length rows per SELL slice, aggregates stay the exact
 // slabs of the caller's order) and everything is rebuilt in that order.
-std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology& t) {
+std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology& t, const gmpnp_partition_t* part) {
   Topology first;
-  std::string err = build_pass(m, m.perm, nf, nagg_req, false, first);
+  std::string err = build_pass(m, m.perm, nf, nagg_req, false, first, part);
   if (!err.empty()) return err;
   std::vector<int32_t> perm2(first.perm);
   if (m.dim != 1)  // interval meshes keep the caller's path order (block-tridiagonal direct solver)
@@ -26,7 +27,7 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
       const int ia = first.iperm[a], ib = first.iperm[b];
       return (first.rowptr[ia + 1] - first.rowptr[ia]) > (first.rowptr[ib + 1] - first.rowptr[ib]);
     });
-  err = build_pass(m, perm2.data(), nf, first.nagg, true, t);
+  err = build_pass(m, perm2.data(), nf, first.nagg, true, t, part);
   if (!err.empty()) return err;
   // Elimination order of the block-banded direct solver: the caller's slab order (sorted along the pore axis), NOT the
   // degree-sorted internal order, whose bandwidth is a whole aggregate.
@@ -38,7 +39,8 @@ std::string build_topology(const gmpnp_mesh_t& m, int nf, int nagg_req, Topology
   return "";
 }
 
-static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t) {
+static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int nf, int nagg_req, bool fixed_nagg, Topology& t,
+                              const gmpnp_partition_t* part) {
   if (m.dim != 1 && m.dim != 3) return "mesh.dim must be 1 or 3";
   if (m.n_vertices <= 0 || m.n_cells <= 0 || !m.coords || !m.cells) return "empty mesh";
   t.dim = m.dim; t.nf = nf; t.nn = m.dim + 1; t.nv = m.n_vertices; t.nc = m.n_cells;
@@ -113,9 +115,49 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
   // ---- aggregates: contiguous, equal-count ranges of the internal order -------------------------
   int nagg_max = std::min(kMaxCoarse / nf, 16);  // LDS-resident block Gauss-Jordan must fit in 160 KiB; TileCoarse sums <= 16 column blocks
   while (nagg_max > 1 && (size_t)((nagg_max * nf) * (nagg_max * nf) + nagg_max * nf * nf + 2 * nf * nf) * sizeof(double) > 160u * 1024u) --nagg_max;
+  auto fill_row_aggs = [&]() {  // aggregates each block row touches (at most kMaxRowAggs)
+    t.row_aggs.assign((size_t)nv * kMaxRowAggs, -1);
+    for (int i = 0; i < nv; ++i) {
+      int cnt = 0;
+      for (int k = t.rowptr[i]; k < t.rowptr[i + 1]; ++k) {
+        int g = t.agg[t.cols[k]]; bool seen = false;
+        for (int q = 0; q < cnt; ++q) seen |= (t.row_aggs[(size_t)i * kMaxRowAggs + q] == g);
+        if (!seen) { if (cnt == kMaxRowAggs) return false; t.row_aggs[(size_t)i * kMaxRowAggs + cnt++] = g; }
+      }
+    }
+    return true;
+  };
+  int nagg;
+  t.own_node0 = 0; t.own_node1 = nv; t.own_agg0 = 0;
+  if (part) {
+    // Mesh partition (one handle per rank): the caller numbers the coarse slabs over the WHOLE mesh and tells every
+    // local vertex its slab; the internal order must run through the slabs in ascending order (a slab order of the
+    // local vertices does).  Owned vertices form one contiguous range of whole slabs; ghost vertices lie in slabs
+    // owned by the neighbours, so every tile of the Krylov kernels is either all owned or all ghost.
+    nagg = part->n_global_aggregates;
+    if (nagg < 1 || nagg > nagg_max) return "partition: n_global_aggregates out of range (coarse operator must fit the LDS-resident inverse)";
+    if (!part->vertex_aggregate || !part->vertex_owned) return "partition: vertex_aggregate / vertex_owned missing";
+    t.nagg = nagg; t.agg.resize(nv); t.agg_start.assign(nagg + 1, 0);
+    int prev = 0, first_own = -1, last_own = -1;
+    for (int i = 0; i < nv; ++i) {
+      const int g = part->vertex_aggregate[t.perm[i]];
+      if (g < 0 || g >= nagg) return "partition: vertex_aggregate out of range";
+      if (g < prev) return "partition: the vertex order (perm) must run through the aggregates in ascending order";
+      prev = g; t.agg[i] = g; t.agg_start[g + 1]++;
+      if (part->vertex_owned[t.perm[i]]) { if (first_own < 0) first_own = i; last_own = i; }
+    }
+    for (int g = 0; g < nagg; ++g) t.agg_start[g + 1] += t.agg_start[g];
+    if (first_own < 0) return "partition: no owned vertex";
+    for (int i = first_own; i <= last_own; ++i) if (!part->vertex_owned[t.perm[i]]) return "partition: owned vertices must be contiguous in the vertex order";
+    t.own_node0 = first_own; t.own_node1 = last_own + 1;
+    const int ga = t.agg[first_own], gb = t.agg[last_own];
+    if (t.agg_start[ga] != first_own || t.agg_start[gb + 1] != last_own + 1) return "partition: an aggregate mixes owned and ghost vertices";
+    t.own_agg0 = ga; t.own_agg1 = gb + 1;
+    if (!fill_row_aggs()) return "partition: a block row touches more than kMaxRowAggs aggregates";
+  } else {
   // default: 8 slabs.  On the pore meshes 8..60 slabs give the same Krylov iteration count (the block-Jacobi smoother
   // limits convergence, tools/precond_experiment.py), fewer than 8 lose it, and the coarse set-up cost grows with nagg^3.
-  int nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : std::min(nagg_max, 8);
+  nagg = nagg_req > 0 ? std::min(nagg_req, nagg_max) : std::min(nagg_max, 8);
   nagg = std::max(1, std::min(nagg, nv / 8 > 0 ? nv / 8 : 1));
   if (fixed_nagg) nagg = nagg_req;
   for (;; --nagg) {  // shrink until no row touches more than kMaxRowAggs aggregates
@@ -123,20 +165,13 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
     for (int g = 0; g <= nagg; ++g) t.agg_start[g] = (int32_t)((int64_t)nv * g / nagg);
     for (int g = 0; g < nagg; ++g)
       for (int i = t.agg_start[g]; i < t.agg_start[g + 1]; ++i) t.agg[i] = g;
-    t.row_aggs.assign((size_t)nv * kMaxRowAggs, -1);
-    bool ok = true;
-    for (int i = 0; i < nv && ok; ++i) {
-      int cnt = 0;
-      for (int k = t.rowptr[i]; k < t.rowptr[i + 1]; ++k) {
-        int g = t.agg[t.cols[k]]; bool seen = false;
-        for (int q = 0; q < cnt; ++q) seen |= (t.row_aggs[(size_t)i * kMaxRowAggs + q] == g);
-        if (!seen) { if (cnt == kMaxRowAggs) { ok = false; break; } t.row_aggs[(size_t)i * kMaxRowAggs + cnt++] = g; }
-      }
-    }
+    const bool ok = fill_row_aggs();
     if (ok || nagg == 1) break;
     if (fixed_nagg) return "internal error: aggregate count changed between passes";
   }
   nagg = t.nagg;
+  t.own_agg1 = nagg;
+  }
 
   // ---- SELL slices ------------------------------------------------------------------------------
   // Inside a row the blocks may sit in any order: put the diagonal first and the others by decreasing
@@ -177,6 +212,7 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
   }
   t.nslices = (int)t.slice_node0.size();
   t.ntiles = (int)t.tile_slice0.size();
+  t.own_tile0 = t.agg_tile_ptr[t.own_agg0]; t.own_ntiles = t.agg_tile_ptr[t.own_agg1] - t.own_tile0;
   t.tile_slice0.push_back(t.nslices);
   t.tile_slots = ((t.tile_slots + 7) / 8) * 8;
   t.slice_off.assign(t.nslices + 1, 0); t.slice_colbase.assign(t.nslices + 1, 0);

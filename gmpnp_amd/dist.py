@@ -418,6 +418,184 @@ def newton_solve(ops, comm: Comm, dom: LocalDomain, u, un, maximum_iterations=50
     return u, stats
 
 
+# ---------------------------------------------------------------------------------------------
+# the partitioned solve INSIDE the library (gmpnp_create_partition / gmpnp_group_*): this module only partitions and plans
+# ---------------------------------------------------------------------------------------------
+def default_global_aggregates(nparts: int) -> int:
+    """Coarse slabs over the whole mesh: 8 (the single-GPU default) when the ranks divide it, else one slab per rank
+    rounded up to a multiple of the rank count; at most 15 (the 9-field coarse operator must fit the LDS-resident inverse)."""
+    if 8 % nparts == 0:
+        return 8
+    n = nparts * max(1, 8 // nparts)
+    if n > 15:
+        raise ValueError("no coarse-slab count <= 15 is a multiple of %d ranks" % nparts)
+    return n
+
+
+def partition_plan(prob: Problem, nparts: int, rank: int, n_global_aggregates: int = None):
+    """Everything rank `rank` needs for ``gmpnp_create_partition``: (LocalDomain, local perm, partition dict).
+
+    Global slab order (``backend.slab_permutation``: vertices sorted along the pore axis) is cut into `nparts` contiguous
+    ownership ranges and into `n_global_aggregates` coarse slabs with the SAME integer boundaries, so a slab never
+    straddles two ranks.  The local vertex order handed to the library is the global slab order restricted to the local
+    vertices: ghosts of the lower neighbour, owned vertices, ghosts of the upper neighbour."""
+    from .backend import slab_permutation
+    nag = n_global_aggregates or default_global_aggregates(nparts)
+    if nag % nparts:
+        raise ValueError("n_global_aggregates must be a multiple of the number of ranks")
+    nv = prob.coords.shape[0]
+    gperm = slab_permutation(prob.coords, prob.cells, window=0)
+    pos = np.empty(nv, dtype=np.int64)
+    pos[gperm] = np.arange(nv)
+    bounds = (nv * np.arange(nag + 1, dtype=np.int64)) // nag
+    agg_of = np.searchsorted(bounds[1:], pos, side="right").astype(np.int32)       # slab of every global vertex
+    owner = (agg_of // (nag // nparts)).astype(np.int32)
+    dom = build_local_domain(prob, owner, rank, nparts)
+    lverts = np.concatenate([dom.owned, dom.ghosts])
+    perm_local = np.argsort(pos[lverts], kind="stable").astype(np.int32)
+    nbrs = sorted(set(dom.send) | set(dom.recv))
+    send_ptr, recv_ptr, send_v, recv_v = [0], [0], [], []
+    for q in nbrs:
+        send_v.extend(np.asarray(dom.send.get(q, []), dtype=np.int64).tolist())
+        recv_v.extend(np.asarray(dom.recv.get(q, []), dtype=np.int64).tolist())
+        send_ptr.append(len(send_v))
+        recv_ptr.append(len(recv_v))
+    owned_flag = np.zeros(len(lverts), dtype=np.uint8)
+    owned_flag[:dom.n_owned] = 1
+    part = {"rank": rank, "size": nparts, "n_global_aggregates": nag, "vertex_aggregate": agg_of[lverts], "vertex_owned": owned_flag,
+            "neighbour_rank": np.array(nbrs, dtype=np.int32), "send_ptr": np.array(send_ptr, dtype=np.int32),
+            "send_vertices": np.array(send_v, dtype=np.int32), "recv_ptr": np.array(recv_ptr, dtype=np.int32),
+            "recv_vertices": np.array(recv_v, dtype=np.int32)}
+    return dom, perm_local, part
+
+
+class PartitionedSolver:
+    """One mesh-partitioned problem solved by libgmpnp.so across `nparts` ranks (SURVEY section 8e / BASELINE configs[3]).
+
+    ``PartitionedSolver(prob, nparts)``                every rank in THIS process on one GPU (rehearsal: the exchanges are device
+                                                       copies between the handles) — what a single-GPU box can run;
+    ``PartitionedSolver(prob, nparts, rank=r, ...)``   one rank per process / GPU; the RCCL communicator is created inside the
+                                                       library from an id that rank 0 makes and ``torch.distributed`` broadcasts.
+    The Krylov and Newton loops run in the library; Python only scatters / gathers states and per-step boundary values."""
+
+    def __init__(self, prob: Problem, nparts: int, rank: int = None, device_id: int = 0, n_global_aggregates: int = None,
+                 use_torch_dist: bool = True, **device_kwargs):
+        from ctypes import byref, c_void_p, create_string_buffer
+        from . import backend
+        self.backend = backend
+        self.lib = backend.load_library()
+        self.nparts, self.rank = nparts, rank
+        self.nv_global, self.nf = prob.coords.shape[0], prob.nf
+        self.ranks = list(range(nparts)) if rank is None else [rank]
+        self.doms, self.devs = [], []
+        for r in self.ranks:
+            dom, perm, part = partition_plan(prob, nparts, r, n_global_aggregates)
+            self.doms.append(dom)
+            self.devs.append(backend.DeviceSolver(dom.problem, device_id=device_id, perm=perm, partition=part, **device_kwargs))
+        self._comm = c_void_p()
+        if rank is not None:
+            idbuf = create_string_buffer(backend.COMM_ID_BYTES)
+            if nparts > 1 or use_torch_dist:
+                import torch
+                import torch.distributed as tdist
+                if tdist.is_available() and tdist.is_initialized():
+                    if rank == 0:
+                        self._check(self.lib.gmpnp_comm_unique_id(idbuf))
+                    dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+                    t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=dev)
+                    tdist.broadcast(t, src=0)
+                    idbuf = create_string_buffer(bytes(t.cpu().tolist()), backend.COMM_ID_BYTES)
+                elif nparts == 1:
+                    self._check(self.lib.gmpnp_comm_unique_id(idbuf))
+                else:
+                    raise RuntimeError("torch.distributed is not initialised: the communicator id cannot reach the other ranks")
+            else:
+                self._check(self.lib.gmpnp_comm_unique_id(idbuf))
+            self._check(self.lib.gmpnp_comm_create(idbuf, rank, nparts, device_id, byref(self._comm)))
+        handles = (c_void_p * len(self.devs))(*[d._h for d in self.devs])
+        self._group = c_void_p()
+        self._check(self.lib.gmpnp_group_create(len(self.devs), handles, self._comm if rank is not None else None, byref(self._group)))
+
+    def _check(self, code):
+        if code != self.backend.OK:
+            raise self.backend.GmpnpError(code, self.lib.gmpnp_last_error().decode())
+
+    # ---- state in GLOBAL (file) vertex order -------------------------------------------------------------------------
+    def set_state(self, u_global=None, un_global=None):
+        for dom, dev in zip(self.doms, self.devs):
+            dev.set_state(None if u_global is None else scatter_local(dom, np.asarray(u_global)),
+                          None if un_global is None else scatter_local(dom, np.asarray(un_global)))
+
+    def set_dirichlet(self, dofs, vals):
+        """The GLOBAL Dirichlet set (file-order dofs); every local handle gets its part + identity rows on its ghost dofs."""
+        nf = self.nf
+        dofs, vals = np.asarray(dofs, dtype=np.int64), np.asarray(vals, dtype=np.float64)
+        for dom, dev in zip(self.doms, self.devs):
+            lverts = np.concatenate([dom.owned, dom.ghosts])
+            g2l = -np.ones(self.nv_global, dtype=np.int64)
+            g2l[lverts] = np.arange(len(lverts))
+            lv = g2l[dofs // nf]
+            keep = lv >= 0
+            table = dict(zip((lv[keep] * nf + dofs[keep] % nf).tolist(), vals[keep].tolist()))
+            for d in range(dom.n_owned * nf, len(lverts) * nf):
+                table[d] = 0.0
+            bd = np.array(sorted(table), dtype=np.int64)
+            dev.set_dirichlet(bd, np.array([table[d] for d in bd]))
+
+    def owned_state(self, previous=False):
+        """[(owned global vertex ids, (n_owned, nf) values)] of the local ranks."""
+        out = []
+        for dom, dev in zip(self.doms, self.devs):
+            out.append((dom.owned, dev.get_state(previous).reshape(-1, self.nf)[:dom.n_owned]))
+        return out
+
+    def get_state(self):
+        """Global state (file order) — complete in the in-process form; with one rank per process all-gathered through
+        torch.distributed when it is initialised, else only this rank's rows are filled."""
+        out = np.zeros((self.nv_global, self.nf))
+        for ids, vals in self.owned_state():
+            out[ids] = vals
+        if self.rank is not None and self.nparts > 1:
+            import torch
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+                t = torch.from_numpy(out).to(dev)
+                tdist.all_reduce(t)
+                out = t.cpu().numpy()
+        return out.ravel()
+
+    def newton_solve(self, options, error_on_nonconvergence=True):
+        from ctypes import byref
+        st = self.backend.CNewtonStats()
+        code = self.lib.gmpnp_group_newton_solve(self._group, byref(options), byref(st))
+        stats = self.backend.DeviceSolver.stats_dict(st)
+        if code == self.backend.ERR_NOT_CONVERGED and not error_on_nonconvergence:
+            return stats
+        self._check(code)
+        return stats
+
+    def assign_previous(self):
+        self._check(self.lib.gmpnp_group_assign_previous(self._group))
+
+    def close(self):
+        if getattr(self, "_group", None):
+            self.lib.gmpnp_group_destroy(self._group)
+            self._group = None
+        for d in getattr(self, "devs", []):
+            d.close()
+        self.devs = []
+        if getattr(self, "_comm", None) and self._comm.value:
+            self.lib.gmpnp_comm_destroy(self._comm)
+            self._comm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def gather_global(comm: Comm, dom: LocalDomain, u_local, nv_global):
     """Assemble the global (file-order) state on every rank from the owned parts (all-reduce of disjoint pieces)."""
     nf = dom.nf

@@ -243,6 +243,53 @@ int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev,
 int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev);
 int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t kind, const double* r_dev, double* z_dev);
 
+/* ---- mesh-partitioned solve (no reference counterpart: the reference is a serial script) -------------
+ * One handle per rank on the rank's LOCAL mesh = every cell that touches an owned vertex; the other vertices of those cells
+ * are ghosts (owned by a neighbouring rank), flagged as Dirichlet dofs by the caller so that their matrix rows are identity
+ * rows.  Cut cells are assembled on both sides, so owned rows are complete without matrix communication.  Inside the
+ * library: ghost rows of (r, v, p) / (s, t) travel after each BiCGStab half-iteration (grouped ncclSend/ncclRecv on the
+ * solver's stream), the dot products and the coarse restrictions of a half-iteration travel in ONE ncclAllReduce, the
+ * coarse operator is GLOBAL (slabs numbered over the whole mesh, one all-reduce of the Galerkin matrix per set-up, inverted
+ * redundantly by every rank).  gmpnp_amd/dist.py builds the partition and the plan. */
+typedef struct {
+  int32_t rank, size;
+  int32_t n_global_aggregates;       /* coarse slabs over the WHOLE mesh (<= 15 for 9 fields) */
+  const int32_t* vertex_aggregate;   /* [n_vertices] slab of each LOCAL vertex (local mesh-file order); mesh.perm must run
+                                        through the slabs in ascending order */
+  const uint8_t* vertex_owned;       /* [n_vertices] 1 = owned by this rank, 0 = ghost; a slab is all owned or all ghost */
+  int32_t n_neighbours;
+  const int32_t* neighbour_rank;     /* [n_neighbours] */
+  const int32_t* send_ptr;           /* [n_neighbours+1] into send_vertices */
+  const int32_t* send_vertices;      /* local vertices whose rows go to neighbour q, in q's receive order */
+  const int32_t* recv_ptr;           /* [n_neighbours+1] into recv_vertices */
+  const int32_t* recv_vertices;      /* local ghost vertices filled from neighbour q, in q's send order */
+} gmpnp_partition_t;
+
+int gmpnp_create_partition(const gmpnp_mesh_t* local_mesh, const gmpnp_model_t* model, const gmpnp_quadrature_t* quad,
+                           const gmpnp_options_t* opts, const gmpnp_partition_t* part, gmpnp_solver** out);
+
+/* RCCL communicator of the ranks (one process per GPU).  Rank 0 makes the id and hands the 128 bytes to the others by any
+ * means (the Python driver broadcasts them with torch.distributed); every rank then joins.  librccl.so is loaded on first
+ * use; its absence is an error here, not at library load. */
+#define GMPNP_COMM_ID_BYTES 128
+typedef struct gmpnp_comm gmpnp_comm;
+int gmpnp_comm_unique_id(char id[GMPNP_COMM_ID_BYTES]);
+int gmpnp_comm_create(const char id[GMPNP_COMM_ID_BYTES], int32_t rank, int32_t size, int32_t device_id, gmpnp_comm** out);
+void gmpnp_comm_destroy(gmpnp_comm* c);
+
+/* The partition handles ONE PROCESS drives: exactly one with a communicator (production: one rank per GPU), or all `size`
+ * of them with comm = NULL (rehearsal of the whole partitioned algorithm inside one process on one GPU: the exchanges
+ * become device copies between the handles; this is what the single-GPU test box runs). */
+typedef struct gmpnp_group gmpnp_group;
+int gmpnp_group_create(int32_t n_local, gmpnp_solver* const* handles, gmpnp_comm* comm, gmpnp_group** out);
+void gmpnp_group_destroy(gmpnp_group* g);
+/* solve(F == 0, u, bcs, solver_parameters) on the partitioned state (each handle's u / u_n hold owned + ghost values, set
+ * with gmpnp_set_state; ghost values of u are kept current inside).  Collective: every rank calls it.  Statistics are
+ * identical on all ranks.  Linear solver: GMPNP_LINEAR_BICGSTAB_TWOLEVEL or _JACOBI. */
+int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* opts, gmpnp_newton_stats_t* stats);
+/* u_n.assign(u) on every local handle. */
+int gmpnp_group_assign_previous(gmpnp_group* g);
+
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
  * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming
