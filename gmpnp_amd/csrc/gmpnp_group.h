@@ -35,10 +35,19 @@ RcclApi* rccl_api(std::string* why) {
   static std::string err;
   if (!tried) {
     tried = true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // One RCCL per HIP runtime.  A process that imported PyTorch first already holds PyTorch's own librccl.so (and this
+    // library then runs on PyTorch's HIP runtime, matched by soname): reuse it.  Otherwise load the system library under
+    // its SONAME only, so that a later `import torch` (which asks for "librccl.so" / "libamdhip64.so" by those names and
+    // finds its bundled copies) keeps its own consistent pair instead of binding to ours.
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
       if (api.lib) break;
     }
+    if (!api.lib)
+      for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+      }
     if (!api.lib) err = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
     else {
       auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p && err.empty()) err = std::string("librccl.so lacks ") + n; return p; };

@@ -527,20 +527,22 @@ class PartitionedSolver:
                           None if un_global is None else scatter_local(dom, np.asarray(un_global)))
 
     def set_dirichlet(self, dofs, vals):
-        """The GLOBAL Dirichlet set (file-order dofs); every local handle gets its part + identity rows on its ghost dofs."""
+        """The GLOBAL Dirichlet set (file-order dofs); every local handle gets its part + identity rows on its ghost dofs
+        (their values never enter anything: ghost rows are masked out of the residual)."""
         nf = self.nf
         dofs, vals = np.asarray(dofs, dtype=np.int64), np.asarray(vals, dtype=np.float64)
-        for dom, dev in zip(self.doms, self.devs):
-            lverts = np.concatenate([dom.owned, dom.ghosts])
-            g2l = -np.ones(self.nv_global, dtype=np.int64)
-            g2l[lverts] = np.arange(len(lverts))
+        if not hasattr(self, "_g2l"):
+            self._g2l, self._ghost_dofs = [], []
+            for dom in self.doms:
+                lverts = np.concatenate([dom.owned, dom.ghosts])
+                g2l = -np.ones(self.nv_global, dtype=np.int64)
+                g2l[lverts] = np.arange(len(lverts))
+                self._g2l.append(g2l)
+                self._ghost_dofs.append(np.arange(dom.n_owned * nf, len(lverts) * nf, dtype=np.int64))
+        for g2l, gh, dom, dev in zip(self._g2l, self._ghost_dofs, self.doms, self.devs):
             lv = g2l[dofs // nf]
-            keep = lv >= 0
-            table = dict(zip((lv[keep] * nf + dofs[keep] % nf).tolist(), vals[keep].tolist()))
-            for d in range(dom.n_owned * nf, len(lverts) * nf):
-                table[d] = 0.0
-            bd = np.array(sorted(table), dtype=np.int64)
-            dev.set_dirichlet(bd, np.array([table[d] for d in bd]))
+            keep = (lv >= 0) & (lv < dom.n_owned)
+            dev.set_dirichlet(np.concatenate([lv[keep] * nf + dofs[keep] % nf, gh]), np.concatenate([vals[keep], np.zeros(len(gh))]))
 
     def owned_state(self, previous=False):
         """[(owned global vertex ids, (n_owned, nf) values)] of the local ranks."""

@@ -41,7 +41,10 @@ def output_root():
 class PoreRun:
     """State of one pore simulation; ``step()`` is one pass of the reference's time loop body (3D:783-858)."""
 
-    def __init__(self, num_steps=None, as_published=False, device_kwargs=None, solver_parameters=None, refine=0, **kwargs):
+    def __init__(self, num_steps=None, as_published=False, device_kwargs=None, solver_parameters=None, refine=0,
+                 partition=None, **kwargs):
+        """``partition`` = (nparts, rank): solve this ONE problem across `nparts` mesh partitions (rank None: all of them in
+        this process on one GPU; rank r: this process is rank r of a ``torch.distributed`` job, RCCL inside the library)."""
         self.kwargs = kwargs
         self.pp = pore_parameters(as_published=as_published, **kwargs)
         self.mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), self.pp.mesh_name))
@@ -49,7 +52,11 @@ class PoreRun:
         if refine:  # uniformly refined copy of the reference mesh (not a reference feature: roofline studies)
             from .mesh import Mesh
             self.mesh = Mesh(dim=3, coords=self.problem.coords, cells=self.problem.cells)
-        self.sys = GMPNPSystem(self.problem, **(device_kwargs or {}))
+        if partition:
+            from .solver import PartitionedSystem
+            self.sys = PartitionedSystem(self.problem, partition[0], rank=partition[1], **(device_kwargs or {}))
+        else:
+            self.sys = GMPNPSystem(self.problem, **(device_kwargs or {}))
         self.solver_parameters = solver_parameters or SOLVER_PARAMETERS
         self.tot_num_steps = self.pp.tot_num_steps if num_steps is None else int(num_steps)
         nv = self.mesh.num_vertices

@@ -60,6 +60,53 @@ class GMPNPSystem:
         self.dev.close()
 
 
+class PartitionedSystem:
+    """The same operator surface on ONE problem cut into `nparts` mesh partitions (BASELINE configs[3]):
+    the Newton and BiCGStab loops run inside libgmpnp.so across the ranks (gmpnp_group_newton_solve).  `rank` = None keeps
+    every rank in this process (one GPU, rehearsal); `rank` = r is the one-process-per-GPU form over RCCL."""
+
+    def __init__(self, problem: Problem, nparts: int, rank: int = None, **device_kwargs):
+        from .dist import PartitionedSolver
+        self.problem = problem
+        self.ps = PartitionedSolver(problem, nparts, rank=rank, **device_kwargs)
+        self.dev = self.ps.devs[0]
+        self.nv = problem.coords.shape[0]
+        self.nf = problem.nf
+        self.newton_iterations = 0
+        self.krylov_iterations = 0
+        self.last_stats = None
+
+    def initialise(self, u0_values):
+        u_n = np.tile(np.asarray(u0_values, dtype=np.float64), self.nv)
+        self.ps.set_state(np.zeros(self.problem.ndof), u_n)
+
+    def set_bcs(self, dofs, vals):
+        self.problem.bc_dofs, self.problem.bc_vals = dofs, vals
+        self.ps.set_dirichlet(dofs, vals)
+
+    def solve(self, solver_parameters=None):
+        opts = backend.newton_options(solver_parameters, dim=3)
+        try:
+            st = self.ps.newton_solve(opts)
+        except backend.GmpnpError as e:
+            if e.code == backend.ERR_NOT_CONVERGED:
+                raise RuntimeError("Newton solver did not converge because maximum number of iterations reached") from e
+            raise
+        self.newton_iterations += st["iterations"]
+        self.krylov_iterations += st["krylov_iterations"]
+        self.last_stats = st
+        return st
+
+    def vertex_values(self):
+        return self.ps.get_state().reshape(self.nv, self.nf)
+
+    def assign_previous(self):
+        self.ps.assign_previous()
+
+    def close(self):
+        self.ps.close()
+
+
 def column_medians(vals, cols):
     """``[np.median(vals[:, c]) for c in cols]`` (reference 3D:817-824 takes the medians of four vertex arrays every
     time step) with one selection pass over a contiguous copy: 45 us instead of 230 us for 4 x 3,679 values.  Same

@@ -129,3 +129,32 @@ def test_partitioned_newton_matches_serial_oracle(tmp_path, use_torch):
     assert np.allclose(got["res"], st.residuals, rtol=1e-5)
     assert np.linalg.norm(got["u"] - u_ref) / np.linalg.norm(u_ref) < 1e-8
     assert got["kits"].max() < 3000
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 4, 8])
+def test_partition_plan_is_consistent(nparts, pore10):
+    """The plan gmpnp_create_partition gets (dist.partition_plan): ownership ranges and coarse slabs share their
+    boundaries, the local vertex order runs through the slabs in ascending order with the owned vertices contiguous, and
+    what rank p sends to q is, entry by entry, what q expects from p."""
+    from gmpnp_amd import dist
+    pp, mesh, prob, _ = pore10
+    plans = [dist.partition_plan(prob, nparts, r) for r in range(nparts)]
+    nv = mesh.num_vertices
+    seen = np.zeros(nv, dtype=int)
+    for r, (dom, perm, part) in enumerate(plans):
+        lverts = np.concatenate([dom.owned, dom.ghosts])
+        seen[dom.owned] += 1
+        ag, own = part["vertex_aggregate"][perm], part["vertex_owned"][perm]
+        assert (np.diff(ag) >= 0).all()
+        first, last = np.nonzero(own)[0][[0, -1]]
+        assert own[first:last + 1].all() and own.sum() == dom.n_owned
+        assert set(ag[own == 1]).isdisjoint(set(ag[own == 0]))                      # a slab is all owned or all ghost
+        assert part["n_global_aggregates"] % nparts == 0
+        for j, q in enumerate(part["neighbour_rank"]):
+            qd, _, qp = plans[q]
+            jj = list(qp["neighbour_rank"]).index(r)
+            mine = lverts[part["send_vertices"][part["send_ptr"][j]:part["send_ptr"][j + 1]]]
+            ql = np.concatenate([qd.owned, qd.ghosts])
+            theirs = ql[qp["recv_vertices"][qp["recv_ptr"][jj]:qp["recv_ptr"][jj + 1]]]
+            assert len(mine) > 0 and np.array_equal(mine, theirs)                   # same global vertices, same order
+    assert (seen == 1).all()

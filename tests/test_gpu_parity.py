@@ -781,6 +781,74 @@ def test_staged_schedule_reproduces_the_recorded_digits(voltage, gpu_lib):
     assert abs(s["eps_rel_OHP"] / eps - 1.0) < 2e-10, s
 
 
+@pytest.mark.parametrize("case,nparts", [("pore10", 2), ("pore10", 4), ("pore10", 8), ("pore50", 4)])
+def test_partitioned_solve_in_library_matches_serial(case, nparts, pore10, pore50, gpu_lib):
+    """ONE problem cut into mesh partitions and solved inside libgmpnp.so (gmpnp_group_newton_solve): global coarse
+    space, one fused all-reduce and one ghost-row exchange per BiCGStab half-iteration.  All ranks live in this process
+    (the test box has one GPU; RCCL refuses two ranks on one device), the exchanges are device copies — every other line
+    of the algorithm is the multi-GPU one.  The serial golden step is reproduced with the same Newton count, and BiCGStab
+    needs about what the single-GPU solver needs (the partitioned preconditioner is the same operator)."""
+    from gmpnp_amd import dist
+    pp, mesh, prob, _ = pore10 if case == "pore10" else pore50
+    g = np.load(os.path.join(GOLDEN, case + "_steps.npz"))
+    nv = mesh.num_vertices
+    un = np.tile(np.r_[np.ones(8), 0.0], nv)
+    opts = gpu_lib.newton_options(MUMPS_09)
+    with gpu_lib.DeviceSolver(prob, warm_start=-1, coarse_refresh=1) as dev:   # cold starts, fresh coarse operator: like the group
+        dev.set_state(np.zeros(nv * 9), un)
+        serial = dev.newton_solve(opts)
+    with dist.PartitionedSolver(prob, nparts) as ps:
+        ps.set_state(np.zeros(nv * 9), un)
+        st = ps.newton_solve(opts)
+        u = ps.get_state()
+    assert st["converged"] and st["iterations"] == int(g["newton_its"][0]) == serial["iterations"]
+    assert relerr(u, g["states"][0]) < 1e-8
+    assert np.allclose(st["residuals"], serial["residuals"], rtol=1e-5)
+    assert st["krylov_iterations"] < 1.3 * serial["krylov_iterations"] + 10, (st["krylov_per_iteration"], serial["krylov_per_iteration"])
+
+
+def test_partitioned_time_loop_matches_golden(gpu_lib):
+    """The 3D driver on two partitions (PoreRun(partition=...)): Newton, global medians -> Sechenov -> new bc4 on every
+    rank's handle, u_n.assign(u) — the golden steps of the serial oracle."""
+    from gmpnp_amd.pore3d import PoreRun
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    run = PoreRun(num_steps=3, concentration_elec=0.5, L=10e-9, R=5e-9, partition=(2, None))
+    try:
+        run.run(verbose=False)
+        assert run.newton_its == list(g["newton_its"][:3])
+        for k in range(3):
+            assert relerr(run.history[k + 1].ravel(), g["states"][k]) < 1e-8
+        assert abs(run.co2_bc - g["co2_bc"][2]) / run.co2_bc < 1e-9
+    finally:
+        run.sys.close()
+
+
+def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
+    """The RCCL transport itself (librccl.so loaded by the library, communicator from gmpnp_comm_unique_id /
+    gmpnp_comm_create, ncclAllReduce on the solver's stream) on the one rank a single-GPU box allows."""
+    from gmpnp_amd import dist
+    pp, mesh, prob, _ = pore10
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    nv = mesh.num_vertices
+    with dist.PartitionedSolver(prob, 1, rank=0, use_torch_dist=False) as ps:
+        ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
+        st = ps.newton_solve(gpu_lib.newton_options(MUMPS_09))
+        u = ps.get_state()
+    assert st["iterations"] == int(g["newton_its"][0]) and relerr(u, g["states"][0]) < 1e-8
+
+
+def test_partition_plans_are_refused_when_inconsistent(pore10, gpu_lib):
+    from gmpnp_amd import dist
+    pp, mesh, prob, _ = pore10
+    dom, perm, part = dist.partition_plan(prob, 2, 0)
+    bad = dict(part)
+    bad["vertex_owned"] = np.ones_like(part["vertex_owned"])      # ghosts declared owned: slabs would mix, lists are wrong
+    with pytest.raises(gpu_lib.GmpnpError):
+        gpu_lib.DeviceSolver(dom.problem, perm=perm, partition=bad)
+    with pytest.raises(gpu_lib.GmpnpError, match="ascending"):
+        gpu_lib.DeviceSolver(dom.problem, perm=perm[::-1].copy(), partition=part)
+
+
 def _partition_worker(rank, world, port, out_dir, resident=False):
     import sys
     from conftest import ROOT
