@@ -823,6 +823,33 @@ def test_partitioned_time_loop_matches_golden(gpu_lib):
         run.sys.close()
 
 
+def test_config3_geometry_on_four_partitions(gpu_lib):
+    """BASELINE configs[3]: L_100_R_50 (mesh generated by gmpnp_amd.meshgen — the reference's file was never published),
+    4 mesh partitions.  With the stated 1.0 M bulk Newton leaves the admissible set (1 - sum a_j u_j <= 0) in the first
+    solve from the zero state, serial and partitioned alike (the oracle diverges on this geometry too, DESIGN section 6);
+    with the 0.5 M bulk of the north-star case the partitioned run reproduces the single-GPU run: same Newton counts,
+    states to round-off of the linear solves."""
+    from gmpnp_amd.pore3d import PoreRun
+    for part in (None, (4, None)):
+        run = PoreRun(num_steps=1, concentration_elec=1.0, L=100e-9, R=50e-9, partition=part)
+        try:
+            with pytest.raises(RuntimeError, match="1 - sum_j a_j u_j <= 0"):
+                run.step(verbose=False)
+        finally:
+            run.sys.close()
+    out = []
+    for part in (None, (4, None)):
+        run = PoreRun(num_steps=3, concentration_elec=0.5, L=100e-9, R=50e-9, partition=part)
+        try:
+            run.run(verbose=False)
+            out.append((list(run.newton_its), np.array(run.history[1:])))
+            assert run.mesh.num_vertices == 11725
+        finally:
+            run.sys.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) == 3
+    assert relerr(out[1][1].ravel(), out[0][1].ravel()) < 1e-8
+
+
 def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
     """The RCCL transport itself (librccl.so loaded by the library, communicator from gmpnp_comm_unique_id /
     gmpnp_comm_create, ncclAllReduce on the solver's stream) on the one rank a single-GPU box allows."""
