@@ -31,6 +31,7 @@ EXPORTS = [
     "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
     "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_destroy", "gmpnp_group_create",
     "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
+    "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
 COMM_ID_BYTES = 128
 
@@ -147,6 +148,8 @@ def load_library(path: str = None):
     lib.gmpnp_group_destroy.restype = None
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
     lib.gmpnp_group_assign_previous.argtypes = [c_void_p]
+    lib.gmpnp_project_gradient.argtypes = [c_void_p, POINTER(c_double), c_double, POINTER(c_double), POINTER(CLinearStats)]
+    lib.gmpnp_project_cellwise.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(CLinearStats)]
     if path is None:
         _lib = lib
     return lib
@@ -394,6 +397,31 @@ class DeviceSolver:
         z = np.empty(self.ndof)
         self._check(self.lib.gmpnp_precond_apply(self._h, linear_solver, _dptr(r), _dptr(z)))
         return z
+
+    def project_gradient(self, f, sign=1.0):
+        """``project(sign*grad(f), W).compute_vertex_values()`` for the P1 field with vertex values f (file order): (nv, dim).
+        Consistent-mass L2 projection on the device (reference 1D:802-805, 3D:884-909)."""
+        f = np.ascontiguousarray(f, dtype=np.float64).ravel()
+        nv = self.ndof // self.nf
+        assert f.size == nv
+        d = self.problem.coords.shape[1]
+        out = np.empty((nv, d))
+        st = CLinearStats()
+        self._check(self.lib.gmpnp_project_gradient(self._h, _dptr(f), float(sign), _dptr(out), byref(st)))
+        self.last_projection_iterations = st.iterations
+        return out
+
+    def project_cellwise(self, values):
+        """``project(f, Y).compute_vertex_values()`` of a cell-wise constant f: values (nc,) or (nc, ncomp <= 4) in file cell order."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        nc = self.problem.cells.shape[0]
+        ncomp = 1 if v.ndim == 1 else v.shape[1]
+        assert v.size == nc * ncomp
+        nv = self.ndof // self.nf
+        out = np.empty((nv, ncomp))
+        st = CLinearStats()
+        self._check(self.lib.gmpnp_project_cellwise(self._h, ncomp, _dptr(v), _dptr(out), byref(st)))
+        return out[:, 0] if v.ndim == 1 else out
 
     def set_supg(self, rho=None, w_index=None):
         """Nodal SUPG parameters (nv, ns) of the PNP stabilisation (reference 1D:597-722), or None to switch it off."""

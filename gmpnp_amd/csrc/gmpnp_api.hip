@@ -58,6 +58,15 @@ double now_ms() {
 
 }  // namespace
 
+// device side of gmpnp_project_gradient / gmpnp_project_cellwise (gmpnp_project.h), allocated on first use
+struct gmpnp_projector {
+  DevBuf<double> cellvol, cellval, mass, diag, f, b, x, r, p, Ap, dpart;
+  double* h_part = nullptr;   // pinned: dot-product partials
+  int nblocks = 0;
+  bool mass_ready = false;
+  ~gmpnp_projector() { if (h_part) (void)hipHostFree(h_part); }
+};
+
 struct gmpnp_solver {
   Topology t;
   gmpnp_model_t model{};
@@ -138,6 +147,7 @@ struct gmpnp_solver {
   DevBuf<int32_t> send_nodes, recv_nodes;
   DevBuf<double> sendbuf, recvbuf, red_i, red_a, red_b, red_norm;
   double* h_red = nullptr;   // pinned [8]: all-reduced ||b||^2 and status bits
+  std::unique_ptr<gmpnp_projector> projector;
 
   ~gmpnp_solver() {
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1608,3 +1618,4 @@ int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int
 }  // extern "C"
 
 #include "gmpnp_group.h"
+#include "gmpnp_project.h"

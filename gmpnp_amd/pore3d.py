@@ -16,7 +16,7 @@ import numpy as np
 from .mesh import read_dolfin_xml, resolve_mesh_path
 from .params import pore_parameters, utilities_dir
 from .problem import pore_dirichlet, pore_problem
-from .solver import GMPNPSystem, column_medians, project_gradient
+from .solver import GMPNPSystem, column_medians
 from .vtk import write_pvd
 
 SOLVER_PARAMETERS = {  # reference 3D:789-798
@@ -116,8 +116,8 @@ class PoreRun:
         # project(+-grad(u_n), W).compute_vertex_values(): flat, component-major (3D:884-909)
         grads = {}
         for i, nme in enumerate(names[:8]):
-            grads[nme] = project_gradient(mesh.coords, mesh.cells, last[:, i]).T.ravel()
-        field_values = project_gradient(mesh.coords, mesh.cells, last[:, 8], sign=-1.0).T.ravel()
+            grads[nme] = self.sys.dev.project_gradient(last[:, i]).T.ravel()
+        field_values = self.sys.dev.project_gradient(last[:, 8], sign=-1.0).T.ravel()
         tau_array = np.linspace(0, pp.T, self.tot_num_steps)
         np.savez(newpath + "arrays_unscaled.npz", H=H["H"], OH=H["OH"], HCO3=H["HCO3"], CO32=H["CO32"], CO2=H["CO2"],
                  CO=H["CO"], H2=H["H2"], cat=H["cat"], p=H["p"], coor=mesh.coords, tau=tau_array,

@@ -122,73 +122,19 @@ def column_medians(vals, cols):
     return np.array([np.mean(p[i, h - 1:h + 1]) for i in range(p.shape[0])])
 
 
-def project_gradient(coords, cells, f, sign=1.0):
-    """``project(sign*grad(f), W).compute_vertex_values()`` for a P1 field (reference 1D:802-805, 3D:884-909):
-    consistent-mass L2 projection of the cell-wise constant gradient.  Post-processing, run once
-    after the time loop on the host with SciPy's sparse LU — it is not part of the hot path.  Returns (nv, d)."""
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
-    nv, d = coords.shape
-    nn = d + 1
-    X = coords[cells]
-    if d == 1:
-        h = X[:, 1, 0] - X[:, 0, 0]
-        vol = np.abs(h)
-        g = np.zeros((len(cells), 2, 1))
-        g[:, 0, 0], g[:, 1, 0] = -1.0 / h, 1.0 / h
-    else:
-        T = X[:, 1:, :] - X[:, :1, :]
-        Tinv = np.linalg.inv(T)
-        g = np.empty((len(cells), 4, 3))
-        g[:, 1:, :] = np.transpose(Tinv, (0, 2, 1))
-        g[:, 0, :] = -g[:, 1:, :].sum(axis=1)
-        vol = np.abs(np.linalg.det(T)) / 6.0
-    M = (np.ones((nn, nn)) + np.eye(nn)) / ((d + 1) * (d + 2))
-    rows = np.repeat(cells, nn, axis=1).ravel()
-    cols = np.tile(cells, (1, nn)).ravel()
-    Mg = sp.coo_matrix(((M[None] * vol[:, None, None]).ravel(), (rows, cols)), shape=(nv, nv)).tocsc()
-    lu = spla.splu(Mg)
-    gradf = np.einsum("ea,ead->ed", f[cells], g)
-    out = np.empty((nv, d))
-    for k in range(d):
-        rhs = np.bincount(cells.ravel(), weights=np.repeat(sign * gradf[:, k] * vol / nn, nn), minlength=nv)
-        out[:, k] = lu.solve(rhs)
-    return out
-
-
-def project_cellwise(coords, cells, values):
-    """``project(f, Y).compute_vertex_values()`` of a cell-wise constant f onto P1 (reference 1D:599
-    ``project(CellDiameter(mesh))``, 1D:651-653 ``project(sqrt(inner(grad(u_np), grad(u_np))))``): consistent-mass L2
-    projection, host SciPy like the reference's own per-step NumPy post-processing around its solve."""
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
-    nv, d = coords.shape
-    nn = d + 1
-    X = coords[cells]
-    if d == 1:
-        vol = np.abs(X[:, 1, 0] - X[:, 0, 0])
-    else:
-        vol = np.abs(np.linalg.det(X[:, 1:] - X[:, :1])) / 6.0
-    M = (np.ones((nn, nn)) + np.eye(nn)) / ((d + 1) * (d + 2))
-    rows = np.repeat(cells, nn, axis=1).ravel()
-    cols = np.tile(cells, (1, nn)).ravel()
-    Mg = sp.coo_matrix(((M[None] * vol[:, None, None]).ravel(), (rows, cols)), shape=(nv, nv)).tocsc()
-    rhs = np.bincount(cells.ravel(), weights=np.repeat(values * vol / nn, nn), minlength=nv)
-    return spla.splu(Mg).solve(rhs)
-
-
-def supg_parameters(coords, cells, z, p_prev, h_vertex=None, fact=1.0, tol=1.0e-14):
+def supg_parameters(coords, cells, z, p_prev, project_cellwise, h_vertex=None, fact=1.0, tol=1.0e-14):
     """Nodal SUPG parameters of the PNP stabilisation, reference 1D:597-670 (1D meshes): Pe_i = fact h |grad p| |z_i| / 2
     at the vertices (h = projected cell diameter, |grad p| = projected gradient norm of the PREVIOUS step's potential);
     rho_i = fact h / (2 |z_i| |grad p|) where Pe_i > 1 + tol, else fact^2 h^2 / 4; 0 for uncharged species.
-    Returns (rho (nv, ns), h_vertex)."""
+    ``project_cellwise(values)`` is the consistent-mass P1 projection of a cell-wise constant field — in the drivers the
+    device's (``DeviceSolver.project_cellwise`` = gmpnp_project_cellwise).  Returns (rho (nv, ns), h_vertex)."""
     assert coords.shape[1] == 1, "the reference stabilises the 1D script only"
     X = coords[cells]
     length = X[:, 1, 0] - X[:, 0, 0]
     if h_vertex is None:
-        h_vertex = project_cellwise(coords, cells, np.abs(length))
+        h_vertex = project_cellwise(np.abs(length))
     gradp = (p_prev[cells[:, 1]] - p_prev[cells[:, 0]]) / length
-    norm = project_cellwise(coords, cells, np.abs(gradp))
+    norm = project_cellwise(np.abs(gradp))
     z = np.asarray(z, dtype=float)
     rho = np.zeros((coords.shape[0], len(z)))
     rho_small = fact ** 2 * h_vertex ** 2 / 4

@@ -243,6 +243,16 @@ int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev,
 int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev);
 int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t kind, const double* r_dev, double* z_dev);
 
+/* ---- post-processing on the device ------------------------------------------------------------
+ * project(sign * grad(f), W).compute_vertex_values() of a P1 field f given by its vertex values (file order): the
+ * consistent-mass L2 projection of the cell-wise constant gradient the reference computes for `field_values` and the
+ * `<X>_grad` arrays (1D/MPNP_CO2ER_EDL.py:802-805, 3D/MPNP_CO2ER_pore.py:884-909).  out: [n_vertices][dim], row major.
+ * Jacobi-preconditioned CG on the P1 mass matrix to 1e-14 relative residual; stats (may be NULL) reports the iterations. */
+int gmpnp_project_gradient(gmpnp_solver* s, const double* nodal_values, double sign, double* out, gmpnp_linear_stats_t* stats);
+/* project(f, Y) of a cell-wise constant field with ncomp <= 4 components, cell_values [n_cells][ncomp] in mesh-file cell order
+ * (reference 1D:599 project(CellDiameter(mesh)), 1D:651-653 the projected gradient norm of the SUPG parameters). out: [n_vertices][ncomp]. */
+int gmpnp_project_cellwise(gmpnp_solver* s, int32_t ncomp, const double* cell_values, double* out, gmpnp_linear_stats_t* stats);
+
 /* ---- mesh-partitioned solve (no reference counterpart: the reference is a serial script) -------------
  * One handle per rank on the rank's LOCAL mesh = every cell that touches an owned vertex; the other vertices of those cells
  * are ghosts (owned by a neighbouring rank), flagged as Dirichlet dofs by the caller so that their matrix rows are identity

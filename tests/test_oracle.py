@@ -233,19 +233,24 @@ def test_supg_terms_jacobian_is_the_derivative(dim):
 
 
 def test_supg_parameters_product_side_equals_oracle(edl1):
-    """gmpnp_amd.solver.supg_parameters (host glue of the driver) against the oracle's restatement of 1D:597-670, including
-    nodes on both branches of the Peclet switch."""
-    from gmpnp_amd.solver import project_cellwise, supg_parameters
+    """The Peclet switch of gmpnp_amd.solver.supg_parameters (host glue of the driver; its two projections run on the
+    device in the product, here they are handed the oracle's projection) against the oracle's restatement of 1D:597-670,
+    including nodes on both branches.  The device projection itself is checked against the oracle's in the GPU tests."""
+    from gmpnp_amd.solver import supg_parameters
     ep, mesh, prob = edl1
     nv = mesh.num_vertices
     p = -5.0 * np.exp(-mesh.coords[:, 0] * 1.0e4) - 40.0 * mesh.coords[:, 0] ** 2  # steep near x = 0 (Pe > 1), gentle outside
-    r_prod, h_prod = supg_parameters(mesh.coords, mesh.cells, prob.model.z, p)
+
+    def project_cellwise(values):
+        return O.project_cellwise(mesh.coords, mesh.cells, values)
+
+    r_prod, h_prod = supg_parameters(mesh.coords, mesh.cells, prob.model.z, p, project_cellwise)
     r_orac, h_orac = O.supg_rho(mesh.coords, mesh.cells, prob.model.z, p)
     assert np.allclose(r_prod, r_orac, rtol=1e-13, atol=0) and np.allclose(h_prod, h_orac, rtol=1e-13, atol=0)
     small = (h_orac ** 2 / 4)[:, None] * (np.asarray(prob.model.z) != 0)[None, :]
     on_large = (r_orac != small).any(axis=1)
     assert on_large.any() and (~on_large).any() and not r_orac[:, 4].any()  # both branches; CO2 (z = 0) untouched
-    assert np.allclose(project_cellwise(mesh.coords, mesh.cells, np.full(len(mesh.cells), 3.0)), 3.0)
+    assert np.allclose(project_cellwise(np.full(len(mesh.cells), 3.0)), 3.0)
 
 
 def test_config0_first_newton_solve_diverges_in_the_oracle():

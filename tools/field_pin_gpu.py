@@ -6,7 +6,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from gmpnp_amd.edl1d import EDLRun
-from gmpnp_amd.solver import project_gradient
 REC = {-2.5: (-0.08032108300135771, 74.56149297894756), -5.0: (-0.2524415478848975, 57.64572780716129),
        -7.5: (-0.4612956299192668, 50.16243860179017), -10.0: (-0.6149631587776277, 49.311548142969336),
        -12.5: (-0.7310301485096051, 49.2556833480052)}
@@ -21,7 +20,7 @@ for V, (E, eps) in REC.items():
         run.step(verbose=False)
         if (n + 1) % (nsteps // 8) == 0:
             p = run.history[-1][:, 6]
-            fld = project_gradient(mesh.coords, mesh.cells, p, sign=-1.0)[:, 0]
+            fld = run.sys.dev.project_gradient(p, sign=-1.0)[:, 0]
             out.append(fld[i0] * ep.thermal_voltage / ep.L_n * 1e-9)
     print("V %6.1f recorded %.5f | field_OHP at steps n/8..n: %s | last/recorded %.4f | %.1fs" % (V, E, " ".join("%.5f" % o for o in out), out[-1] / E, time.perf_counter() - t0), flush=True)
     run.sys.close()
