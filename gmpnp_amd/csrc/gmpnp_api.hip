@@ -274,7 +274,7 @@ int launch_res_gather(gmpnp_solver* s) {
 
 template <int DIM, int NF>
 int launch_jac_gather(gmpnp_solver* s) {
-  const int g = grid_for(s->c.n_work * kWave, kVecBlock);
+  const int g = grid_for(s->c.n_work * kWave, kVecBlock);   // n_work = 8 equal runs, each a whole number of workgroups
   hipLaunchKernelGGL((k_jac_gather<DIM, NF>), dim3(g), dim3(kVecBlock), 0, s->stream, s->c);
   if (s->c.n_robin > 0) hipLaunchKernelGGL(k_robin_add, dim3(grid_for(s->c.n_robin, 256)), dim3(256), 0, s->stream, s->c);
   HIP_TRY(hipGetLastError());

@@ -470,13 +470,26 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
 // NF entries of its row of block (I, cols[kpos]) by summing the element contributions in element
 // order and stores them at stride 64 doubles (each store instruction writes 63 contiguous doubles).
 // ---------------------------------------------------------------------------------------------
+// One wave per (slice, block position), as many waves in flight as there are blocks (the kernel is latency bound: a
+// workgroup per slice looping over its positions moved 3x fewer bytes and took 1.2-1.8x longer).  The work list runs slice
+// by slice, and blockIdx is remapped so that a contiguous run of the list lands on ONE XCD (workgroups are dealt to the 8
+// XCDs round robin): the element records around a slice's nodes are then shared through that XCD's L2 by the ~15 waves
+// of the slice and by the neighbouring slices, instead of being fetched by every XCD.
+constexpr int kXcds = 8;
+// wave index into the work list: the list is eight equal runs (gmpnp_topology.cpp), workgroup b works in run b % 8
+__device__ __forceinline__ int xcd_run_wave(const Ctx& c) {
+  const int per = (int)gridDim.x / kXcds;   // workgroups per run (the grid is 8 * per)
+  const int blk = ((int)blockIdx.x % kXcds) * per + (int)blockIdx.x / kXcds;
+  return (blk * kVecBlock + (int)threadIdx.x) >> 6;
+}
 template <int DIM, int NF>
 __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {
   using L = Lay<DIM, NF>;
   constexpr int NS = L::NS, NN = L::NN, G = 2, MB = GMPNP_MAX_BILINEAR;
-  const int wave = (blockIdx.x * kVecBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int wave = xcd_run_wave(c), lane = threadIdx.x & 63;
   if (wave >= c.n_work) return;
   const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
+  if (s < 0) return;   // padding of a run
   const int Iloc = lane / NF, i = lane - Iloc * NF;
   if (Iloc >= c.slice_nn[s]) return;
   const int I = c.slice_node0[s] + Iloc;
@@ -1531,9 +1544,10 @@ __global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, cons
 // As = A Dinv: one wave per (slice, block position) scales the NF-entry row pieces of its block by Dinv of the column node.
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_scale_columns(const Ctx c) {
-  const int wave = (blockIdx.x * kVecBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int wave = xcd_run_wave(c), lane = threadIdx.x & 63;
   if (wave >= c.n_work) return;
   const int s = c.wl_slice[wave], kpos = c.wl_kpos[wave];
+  if (s < 0) return;   // padding of a run
   const int Iloc = lane / NF;
   if (Iloc >= c.slice_nn[s]) return;
   const size_t rec = (size_t)(c.slice_colbase[s] + kpos) * kSlicePad + Iloc;

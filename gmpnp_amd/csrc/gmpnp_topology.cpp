@@ -237,12 +237,28 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
             t.tile_aggs[(size_t)tl * kTileAggs + t.tile_nagg[tl]++] = g;
           }
         }
-  // gather work list, heaviest SELL positions (diagonal blocks) first
-  { int mxall = 0;
-    for (int s = 0; s < t.nslices; ++s) mxall = std::max(mxall, t.slice_colbase[s + 1] - t.slice_colbase[s]);
-    for (int kp = 0; kp < mxall; ++kp)
-      for (int s = 0; s < t.nslices; ++s)
-        if (kp < t.slice_colbase[s + 1] - t.slice_colbase[s]) { t.wl_slice.push_back(s); t.wl_kpos.push_back(kp); } }
+  // Gather work list: one wave per (slice, block position).  Eight runs, one per XCD (k_jac_gather / k_scale_columns map
+  // workgroup b to run b % 8): a run holds a contiguous eighth of the slices, so the element records around those nodes are
+  // shared through ONE XCD's L2, and inside a run the heaviest positions (diagonal blocks: most element contributions) come
+  // first.  Runs are padded to equal length with (-1, 0) entries (a wave that reads slice -1 exits).
+  { constexpr int kRuns = 8, kWavesPerBlock = kVecBlock / kWave;
+    std::vector<std::vector<std::pair<int, int>>> runs(kRuns);
+    size_t longest = 0;
+    for (int g = 0; g < kRuns; ++g) {
+      const int s0 = (int)((int64_t)t.nslices * g / kRuns), s1 = (int)((int64_t)t.nslices * (g + 1) / kRuns);
+      int mxall = 0;
+      for (int s = s0; s < s1; ++s) mxall = std::max(mxall, t.slice_colbase[s + 1] - t.slice_colbase[s]);
+      for (int kp = 0; kp < mxall; ++kp)
+        for (int s = s0; s < s1; ++s)
+          if (kp < t.slice_colbase[s + 1] - t.slice_colbase[s]) runs[g].push_back({s, kp});
+      longest = std::max(longest, runs[g].size());
+    }
+    longest = ((longest + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+    for (int g = 0; g < kRuns; ++g)
+      for (size_t q = 0; q < longest; ++q) {
+        const bool on = q < runs[g].size();
+        t.wl_slice.push_back(on ? runs[g][q].first : -1); t.wl_kpos.push_back(on ? runs[g][q].second : 0);
+      } }
   const int ncolrec = t.slice_colbase[t.nslices];
   t.sell_cols.assign((size_t)ncolrec * kSlicePad, 0); t.sell_aggslot.assign((size_t)ncolrec * kSlicePad, 255);
   t.sell_blk.assign((size_t)ncolrec * kSlicePad, -1);
