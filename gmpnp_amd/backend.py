@@ -29,7 +29,7 @@ EXPORTS = [
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
     "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
-    "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_destroy", "gmpnp_group_create",
+    "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create",
     "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
@@ -142,6 +142,7 @@ def load_library(path: str = None):
     lib.gmpnp_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.gmpnp_comm_create.argtypes = [ctypes.c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
     lib.gmpnp_comm_destroy.argtypes = [c_void_p]
+    lib.gmpnp_comm_selftest.argtypes = [c_void_p, c_int32, POINTER(c_double)]
     lib.gmpnp_comm_destroy.restype = None
     lib.gmpnp_group_create.argtypes = [c_int32, POINTER(c_void_p), c_void_p, POINTER(c_void_p)]
     lib.gmpnp_group_destroy.argtypes = [c_void_p]

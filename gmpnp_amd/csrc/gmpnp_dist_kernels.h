@@ -65,6 +65,15 @@ __global__ __launch_bounds__(256) void k_norm_reduce(const double* __restrict__ 
   }
 }
 
+// three dot-product partial arrays (k_dots3 layout: part[m * nblocks + block]) -> out[0..2]
+__global__ __launch_bounds__(256) void k_dots3_reduce(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double lds[12];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += 256) { v[0] += part[i]; v[1] += part[nblocks + i]; v[2] += part[2 * nblocks + i]; }
+  block_sum<3>(v, lds);
+  if (threadIdx.x == 0) { out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; }
+}
+
 // Galerkin matrix before its all-reduce: rows of aggregates this rank does not own come from ghost (identity) rows
 __global__ __launch_bounds__(256) void k_zero_foreign_rows(double* __restrict__ Ac, int n, int row0, int row1) {
   const int q = blockIdx.x * 256 + threadIdx.x;

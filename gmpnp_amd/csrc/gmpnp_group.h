@@ -205,7 +205,7 @@ int group_setup(gmpnp_group* g, int mode) {
 
 // ---- BiCGStab across the ranks: rhs in kr (owned rows; k_res_gather left it there), ||rhs|| = bnorm (global); leaves y in ky ----
 template <int NF>
-int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st) {
+int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st, bool sized_by_previous = true) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   const int n = g->dom[0]->ncoarse;
   KrylovScalars init{};
@@ -250,7 +250,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     // Bursts: every rank launches the SAME number of iterations (the schedule depends only on the previous solve's count and
     // on `done`, both identical on all ranks), then reads the device's verdict.  Iterations launched behind the end of the
     // solve exit at their first instruction; their collectives still pair up.
-    int burst = std::max(2, (7 * g->last_iters) / 8);
+    int burst = sized_by_previous ? std::max(2, (7 * g->last_iters) / 8) : 4;
     gmpnp_solver* s0 = g->dom[0];
     while (true) {
       for (int it = 0; it < burst; ++it) { rc = iteration(); if (rc) return rc; }
@@ -276,7 +276,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
 
 // x = Dinv (I + P Aci P^T) y on the owned rows, ghost rows from their owners, then u -= omega x on every local row
 template <int NF>
-int group_update(gmpnp_group* g, int mode, double omega) {
+int group_update(gmpnp_group* g, int mode, double omega, bool add_to_start) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   const int n = g->dom[0]->ncoarse;
   if (use_coarse) {
@@ -288,7 +288,8 @@ int group_update(gmpnp_group* g, int mode, double omega) {
   }
   for (gmpnp_solver* s : g->dom)
     hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->ky.p,
-                       (const double*)s->cpart_v0.p, s->kx.p, 0.0, 1.0, NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0}, (const double*)s->red_i.p);
+                       (const double*)s->cpart_v0.p, s->kx.p, add_to_start ? 1.0 : 0.0, 1.0, NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0},
+                       (const double*)s->red_i.p);
   int rc = group_exchange(g, NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kx.p; return w; }); if (rc) return rc;
   for (gmpnp_solver* s : g->dom)
     hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p, -omega, (int)s->ndof);
@@ -314,11 +315,41 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
     for (gmpnp_solver* s : g->dom) { rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc; s->jacobian_valid = true; }
     rc = group_setup<NF>(g, o.linear_solver); if (rc) return rc;
     gmpnp_linear_stats_t ls{};
-    rc = group_krylov<NF>(g, o.linear_solver, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, o.krylov_maximum_iterations, &ls);
+    // Warm start, as in the single-GPU Newton (gmpnp_api.hip): with the damped update consecutive corrections satisfy
+    // dx_{k+1} = (1 - w) dx_k + O(|dx_k|^2); x0 = (1-w) dx_k [+ (1-w)^2 (dx_k - (1-w) dx_{k-1})] is accepted when it removes at
+    // least half of the residual (one SpMV, three all-reduced dot products, a decision identical on every rank), and
+    // BiCGStab then only has to remove b - J x0, to the SAME absolute target.
+    const double tol_abs = std::max(o.krylov_relative_tolerance * r, o.krylov_absolute_tolerance);
+    const double q = 1.0 - o.relaxation_parameter;
+    bool warm = false; double rstart = r;
+    if (g->dom[0]->warm_start && st.iterations > 0 && q != 0.0 && r > 0.0) {
+      const double wa = (g->dom[0]->warm_start > 1 && st.iterations > 1) ? q + q * q : q, wb = (g->dom[0]->warm_start > 1 && st.iterations > 1) ? -q * q * q : 0.0;
+      for (gmpnp_solver* s : g->dom) {
+        const int n = s->ndof;
+        hipLaunchKernelGGL(k_warm_start, dim3(grid_for(n, 256)), dim3(256), 0, s->stream, s->kx.p, s->kxp.p, wa, wb, n);
+        hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+        hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->kt.p, (const double*)s->kb.p, s->c.part_f, n,
+                           s->n_resblocks, s->t.own_node0 * NF, s->t.own_node1 * NF);
+        hipLaunchKernelGGL(k_dots3_reduce, dim3(1), dim3(256), 0, s->stream, (const double*)s->c.part_f, s->n_resblocks, s->red_norm.p);
+      }
+      rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_norm.p; }, 3); if (rc) return rc;
+      gmpnp_solver* s0 = g->dom[0];
+      HIP_TRY(hipMemcpyAsync(s0->h_red, s0->red_norm.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
+      HIP_TRY(hipStreamSynchronize(s0->stream));
+      const double wbd = s0->h_red[0], ww = s0->h_red[1], bb = s0->h_red[2], rn2 = bb - 2.0 * wbd + ww;
+      if (rn2 == rn2 && rn2 >= 0.0 && rn2 < 0.25 * bb) {
+        for (gmpnp_solver* s : g->dom)
+          hipLaunchKernelGGL(k_start_residual, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->kr.p, (const double*)s->kb.p, (const double*)s->kt.p, (int)s->ndof);
+        warm = true; rstart = std::sqrt(rn2);
+      }
+    }
+    if (warm && rstart <= tol_abs) { ls.converged = 1; ls.residual_norm = rstart; for (gmpnp_solver* s : g->dom) HIP_TRY(hipMemsetAsync(s->ky.p, 0, s->ndof * sizeof(double), s->stream)); }
+    else rc = group_krylov<NF>(g, o.linear_solver, rstart, warm ? 0.0 : o.krylov_relative_tolerance, warm ? tol_abs : o.krylov_absolute_tolerance,
+                               o.krylov_maximum_iterations, &ls, st.iterations > 0);
     if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
     st.krylov_iterations += ls.iterations;
     if (rc) return rc;
-    rc = group_update<NF>(g, o.linear_solver, o.relaxation_parameter); if (rc) return rc;
+    rc = group_update<NF>(g, o.linear_solver, o.relaxation_parameter, warm); if (rc) return rc;
     st.iterations++;
     rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
     if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
@@ -363,6 +394,38 @@ int gmpnp_comm_create(const char id[GMPNP_COMM_ID_BYTES], int32_t rank, int32_t 
   c->rank = rank; c->size = size; c->device = device_id;
   NCCL_TRY(api, api->CommInitRank(&c->comm, size, u, rank));
   *out = c.release();
+  return GMPNP_OK;
+}
+
+// Round trip through every RCCL entry point the partitioned solve uses, on this rank alone: n doubles sent to OUR OWN rank
+// and received back inside one group (RCCL pairs a send-to-self with the matching receive), then all-reduced.  A single-GPU
+// box cannot host a second rank (RCCL refuses two ranks on one device), so this is how the send/receive bindings get
+// exercised there.  Collective in the sense that every rank of the communicator has to call it (the all-reduce).
+int gmpnp_comm_selftest(gmpnp_comm* c, int32_t n, double* max_error) {
+  if (!c || n < 1 || !max_error) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  RcclApi* api = rccl_api(nullptr);
+  if (!api) return fail(GMPNP_ERR_HIP, "RCCL not loaded");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st; HIP_TRY(hipStreamCreate(&st));
+  DevBuf<double> a, b;
+  HIP_TRY(a.alloc(n)); HIP_TRY(b.alloc(n));
+  std::vector<double> h(n), back(n);
+  for (int i = 0; i < n; ++i) h[i] = 0.25 * i - 3.0 + c->rank;
+  HIP_TRY(hipMemcpyAsync(a.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, st));
+  NCCL_TRY(api, api->GroupStart());
+  NCCL_TRY(api, api->Send(a.p, (size_t)n, ncclDouble, c->rank, c->comm, st));
+  NCCL_TRY(api, api->Recv(b.p, (size_t)n, ncclDouble, c->rank, c->comm, st));
+  NCCL_TRY(api, api->GroupEnd());
+  NCCL_TRY(api, api->AllReduce(b.p, b.p, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  HIP_TRY(hipMemcpyAsync(back.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipStreamDestroy(st);
+  double err = 0.0;
+  for (int i = 0; i < n; ++i) {   // sum over ranks r of (0.25 i - 3 + r)
+    const double want = c->size * (0.25 * i - 3.0) + 0.5 * c->size * (c->size - 1);
+    err = std::max(err, std::fabs(back[i] - want));
+  }
+  *max_error = err;
   return GMPNP_OK;
 }
 

@@ -1670,11 +1670,11 @@ __global__ __launch_bounds__(kVecBlock) void k_true_residual(const double* __res
 
 // Test of a warm start: partials of (w,b), (w,w), (b,b) with w = J x0 (from k_spmv_plain), three per workgroup.
 __global__ __launch_bounds__(kVecBlock) void k_dots3(const double* __restrict__ w, const double* __restrict__ b,
-                                                     double* __restrict__ part, int n, int nblocks) {
+                                                     double* __restrict__ part, int n, int nblocks, int lo = 0, int hi = 0x7fffffff) {
   __shared__ double lds[12];
   const int i = blockIdx.x * kVecBlock + threadIdx.x;
   double v[3] = {0.0, 0.0, 0.0};
-  if (i < n) { const double wi = w[i], bi = b[i]; v[0] = wi * bi; v[1] = wi * wi; v[2] = bi * bi; }
+  if (i < n && i >= lo && i < hi) { const double wi = w[i], bi = b[i]; v[0] = wi * bi; v[1] = wi * wi; v[2] = bi * bi; }   // [lo, hi): the owned dofs of a partitioned handle
   block_sum<3>(v, lds);
   if (threadIdx.x == 0) { part[blockIdx.x] = v[0]; part[nblocks + blockIdx.x] = v[1]; part[2 * nblocks + blockIdx.x] = v[2]; }
 }

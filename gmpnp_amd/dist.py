@@ -567,6 +567,13 @@ class PartitionedSolver:
                 out = t.cpu().numpy()
         return out.ravel()
 
+    def comm_selftest(self, n=4096):
+        """Send-to-self + receive + all-reduce through the library's RCCL bindings; returns the largest error."""
+        from ctypes import byref, c_double
+        err = c_double()
+        self._check(self.lib.gmpnp_comm_selftest(self._comm, n, byref(err)))
+        return err.value
+
     def newton_solve(self, options, error_on_nonconvergence=True):
         from ctypes import byref
         st = self.backend.CNewtonStats()

@@ -285,6 +285,9 @@ int gmpnp_create_partition(const gmpnp_mesh_t* local_mesh, const gmpnp_model_t* 
 typedef struct gmpnp_comm gmpnp_comm;
 int gmpnp_comm_unique_id(char id[GMPNP_COMM_ID_BYTES]);
 int gmpnp_comm_create(const char id[GMPNP_COMM_ID_BYTES], int32_t rank, int32_t size, int32_t device_id, gmpnp_comm** out);
+/* n doubles sent to this rank itself and received back (grouped ncclSend + ncclRecv), then all-reduced over the communicator:
+ * exercises every RCCL entry point of the partitioned solve; max_error = largest deviation from the expected sums. */
+int gmpnp_comm_selftest(gmpnp_comm* c, int32_t n, double* max_error);
 void gmpnp_comm_destroy(gmpnp_comm* c);
 
 /* The partition handles ONE PROCESS drives: exactly one with a communicator (production: one rank per GPU), or all `size`

@@ -889,6 +889,7 @@ def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
     g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
     nv = mesh.num_vertices
     with dist.PartitionedSolver(prob, 1, rank=0, use_torch_dist=False) as ps:
+        assert ps.comm_selftest(5000) == 0.0          # grouped ncclSend/ncclRecv (to self) + ncclAllReduce: exact copies
         ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
         st = ps.newton_solve(gpu_lib.newton_options(MUMPS_09))
         u = ps.get_state()

@@ -13,6 +13,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--threads", type=int, default=1, help="BLAS/OpenMP threads (0 = all cores)")
 ap.add_argument("--out", type=str, default=None)
+ap.add_argument("--first", type=int, default=0, help="first time step of this call (a gpurun call is limited to 20 min: the window is timed in two halves)")
+ap.add_argument("--load", type=str, default=None, help="checkpoint (npz: u, un, co2, accumulated timings) of the previous half")
+ap.add_argument("--save", type=str, default=None)
 a = ap.parse_args()
 nthreads = a.threads if a.threads > 0 else (os.cpu_count() or 1)
 for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -32,9 +35,15 @@ nv, nf = mesh.num_vertices, prob.nf
 u = np.zeros(prob.ndof)
 un = np.tile(np.r_[np.ones(nf - 1), 0.0], nv)
 O.assemble(prob, u, un)   # scatter pattern, once (DOLFIN builds its sparsity pattern once, too)
-its, t_asm, t_lu = [], 0.0, 0.0
+its, t_asm, t_lu, wall_before = [], 0.0, 0.0, 0.0
+if a.load:
+    ck = np.load(a.load)
+    u, un = ck["u"], ck["un"]
+    prob.bc_dofs, prob.bc_vals = pore_dirichlet(pp, bnd, float(ck["co2"]))
+    its, t_asm, t_lu, wall_before = [int(v) for v in ck["its"]], float(ck["t_asm"]), float(ck["t_lu"]), float(ck["wall"])
+    assert len(its) == a.first
 t0 = time.perf_counter()
-for n in range(a.steps):
+for n in range(a.first, a.steps):
     u, st = O.newton_solve(prob, u, un, maximum_iterations=50, relative_tolerance=1e-4, absolute_tolerance=1e-4, relaxation_parameter=0.9)
     u2 = u.reshape(nv, nf)
     co2 = pp.sechenov_co2_scaled(np.median(u2[:, 1]), np.median(u2[:, 2]), np.median(u2[:, 3]), np.median(u2[:, 7]))
@@ -42,10 +51,13 @@ for n in range(a.steps):
     un = u.copy()
     its.append(st.iterations); t_asm += st.t_assemble; t_lu += st.t_linear
     print("step %d: %d Newton iterations, %.1f s so far" % (n, st.iterations, time.perf_counter() - t0), flush=True)
-wall = time.perf_counter() - t0
+wall = wall_before + time.perf_counter() - t0
+if a.save:
+    np.savez(a.save, u=u, un=un, co2=co2, its=np.array(its), t_asm=t_asm, t_lu=t_lu, wall=wall)
 out = {"workload": "3D MPNP_CO2ER_pore L_50_R_5, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0" % (a.steps - 1),
        "kind": "port (CPU oracle: NumPy assembly + SciPy SuperLU; FEniCS/MUMPS not installable)",
-       "threads": nthreads, "host_cpus": os.cpu_count(), "steps": a.steps, "newton_iterations": int(sum(its)),
+       "note": "solve phase only (mesh ingest and the one-off scatter pattern excluded); timed in calls of <= 20 min, state carried over",
+       "threads": nthreads, "host_cpus": os.cpu_count(), "steps": len(its), "newton_iterations": int(sum(its)),
        "newton_per_step": its, "seconds": wall, "assembly_seconds": t_asm, "lu_seconds": t_lu,
        "value": sum(its) / wall, "unit": "Newton-iterations/s"}
 print(json.dumps(out))
