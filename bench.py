@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--mesh", type=str, default="L_50_R_5", help="L_<nm>_R_<nm> pore mesh (default: the north-star mesh)")
     p.add_argument("--refine", type=int, default=0, help="uniform refinements of the mesh (0 = the reference mesh itself)")
     p.add_argument("--replicas-only", action="store_true", help="N > 1: time only the N independent replicas (no partitioned solve)")
+    p.add_argument("--force-partitioned", action="store_true",
+                   help="also at N = 1: run the partitioned phase (one partition, RCCL communicator of one rank) — rehearsal of "
+                        "the N > 1 code path on a one-GPU box; reported under `partitioned_rehearsal`, `value` stays the single-GPU solver's")
     p.add_argument("--partition-timeout", type=int, default=240, help="seconds the partitioned phase may take before the replica result is reported alone")
     return p.parse_args()
 
@@ -113,9 +116,12 @@ def main():
     # hand-over must not wait on workgroups another process keeps off the machine: gmpnp_options_t.shared_device
     shared = int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev
     local = local % ndev
-    if world > 1:
+    if world > 1 or a.force_partitioned:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
@@ -192,7 +198,7 @@ def main():
 
     # ---- N > 1: the north-star quantity — ONE problem, mesh-partitioned over the N GPUs (RCCL inside the library) ------------
     part = None
-    if world > 1 and not a.replicas_only:
+    if (world > 1 or a.force_partitioned) and not a.replicas_only:
         import threading
 
         def bail():
@@ -275,6 +281,8 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(run)
+        if world == 1 and part:
+            out["partitioned_rehearsal"] = part
         if world > 1:
             replicas = {"metric": "newton_iterations_per_sec, %d independent L_50_R_5 problems, one per GPU (BASELINE configs[4] mapping)" % world,
                         "value": its / dt, "ms_per_step": 1e3 * dt / a.steps, "newton_iterations": its, "krylov_iterations": kry, "scaling": "weak"}

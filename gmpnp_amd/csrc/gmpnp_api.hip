@@ -143,6 +143,7 @@ struct gmpnp_solver {
   hipEvent_t ev_poll[2] = {};
   // mesh partition (gmpnp_create_partition): halo plan in INTERNAL node ids, buffers of the fused exchanges
   bool partitioned = false; int part_rank = 0, part_size = 1;
+  bool prereduce = false;   // unpartitioned, many tile slots per aggregate: k_dist_reduce feeds the coarse kernels (Ctx::dist)
   std::vector<int32_t> nb_rank, send_ptr, recv_ptr;   // neighbours; [n_neighbours + 1] offsets into the node lists
   DevBuf<int32_t> send_nodes, recv_nodes;
   DevBuf<double> sendbuf, recvbuf, red_i, red_a, red_b, red_norm;
@@ -375,6 +376,11 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
     if (ev) hipExtLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
     else hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
   }
+  if (s->prereduce) {   // the sums the next coarse kernel reads
+    const int n = s->ncoarse;
+    if (WHICH == 0) hipLaunchKernelGGL(k_dist_reduce, dim3(2 + 3 * n), dim3(256), 0, s->stream, s->c, 1, k & 1, s->red_a.p);
+    else hipLaunchKernelGGL(k_dist_reduce, dim3(4 + n), dim3(256), 0, s->stream, s->c, 2, k & 1, s->red_b.p);
+  }
   s->spmv_launched++;
   return GMPNP_OK;
 }
@@ -413,9 +419,10 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   init.max_iters = maxit; init.done = 0; init.done_next = 0; init.omega = 0.0; init.beta = 0.0;
   init.rr0 = bnorm * bnorm;
   if (!(bnorm > 0.0)) init.done = 1;  // zero right-hand side: dx = 0
-  // one launch: shadow vector (r_0, or GMPNP_SHADOW_B=1 / a random vector after a breakdown), y = 0, P^T r_0 partials
+  // one launch: shadow vector (r_0, or a pseudo-random vector after a breakdown), y = 0, P^T r_0 partials
   // where A(0) expects them, hand-over flags cleared, scalars from the kernel argument
   hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, s->shadow_src, init, s->cpart_v1.p);
+  if (s->prereduce && use_coarse) hipLaunchKernelGGL(k_dist_reduce, dim3(s->ncoarse), dim3(256), 0, s->stream, s->c, 0, 0, s->red_i.p);
   // the previous solve wrote its verdict before the host left its loop and nothing of it writes the mirror afterwards
   volatile HostPoll* hp = s->h_poll;
   hp->done = 0; hp->iters = 0; hp->rr = 0.0;
@@ -497,11 +504,13 @@ template <int NF>
 int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x,
                const NewtonUpdate* upd = nullptr) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
+  const bool pre = s->prereduce && s->c.use_coarse;
   if (s->c.use_coarse)
     hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, src, s->cpart_v0.p);
+  if (pre) hipLaunchKernelGGL(k_dist_reduce, dim3(s->ncoarse), dim3(256), 0, s->stream, s->c, 3, 0, s->red_i.p);
   hipLaunchKernelGGL((k_minv_apply<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, src,
                      (const double*)s->cpart_v0.p, dst, scale_dst, scale_x, upd ? *upd : NewtonUpdate{nullptr, nullptr, 0.0, 0.0, 0.0},
-                     (const double*)nullptr);
+                     pre ? (const double*)s->red_i.p : (const double*)nullptr);
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
 }
@@ -707,7 +716,7 @@ int band_prepare(gmpnp_solver* s) {
   const double gb = (double)n * (2.0 * b + 1.0) * NF * NF * sizeof(double) / 1e9;
   char buf[200];
   if (gb > s->lu_max_gb) {
-    snprintf(buf, sizeof buf, "block-banded LU needs %.1f GB (%d node blocks, band %d), above GMPNP_BAND_LU_MAX_GB = %.1f", gb, n, b, s->lu_max_gb);
+    snprintf(buf, sizeof buf, "block-banded LU needs %.1f GB (%d node blocks, band %d), above gmpnp_options_t.band_lu_max_gb = %.1f", gb, n, b, s->lu_max_gb);
     return fail(GMPNP_ERR_INVALID, buf);
   }
   const size_t ring = (size_t)(b + 1) * NF * sizeof(double);
@@ -834,7 +843,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       // Asynchronous scheme (default): every iteration starts the coarse chain of its matrix on the side stream and solves
       // with the inverse of the previous one; an inverse of THIS matrix is only built in-stream when it has to be.
       // x0 = (1-w) dx_k + (1-w)^2 (dx_k - (1-w) dx_{k-1}): first-order prediction plus the second-order term observed
-      // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (GMPNP_WARM_START=1: first order only)
+      // one iteration earlier, scaled by (1-w)^2 as the quadratic form scales (gmpnp_options_t.warm_start = 1: first order only)
       const double q = 1.0 - o.relaxation_parameter;
       double wa = 0.0, wb = 0.0;
       if (s->warm_start && st.iterations > 0 && q != 0.0) { wa = q; if (s->warm_start > 1 && st.iterations > 1) { wa = q + q * q; wb = -q * q * q; } }
@@ -920,7 +929,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
     st.iterations++;
     ta = now_ms();
     rc = residual<DIM, NF>(s, true, &r, &flags); if (rc) return rc;  // synchronises the stream
-    if (s->phase_timing) {  // GMPNP_PHASE_TIMING=1: device time per phase (five event records and one more wait per iteration)
+    if (s->phase_timing) {  // gmpnp_options_t.phase_timing: device time per phase (five event records and one more wait per iteration)
       float ms01 = 0.f, ms12 = 0.f, ms23 = 0.f, ms3 = 0.f;
       (void)hipEventElapsedTime(&ms01, s->ev_phase[0], s->ev_phase[1]);
       (void)hipEventElapsedTime(&ms12, s->ev_phase[1], s->ev_phase[2]);
@@ -1142,7 +1151,7 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
                po.shared_device ? ", device declared shared" : "");
       return fail(GMPNP_ERR_INVALID, buf);
     }
-    s->fused_half = po.launch_form == 4 ? false : (resident && !po.shared_device);
+    s->fused_half = po.launch_form == 4 ? false : (resident && !po.shared_device && !s->prereduce);
   }
   HIP_TRY(hipHostMalloc((void**)&s->h_part, 3 * std::max(s->n_resblocks, 1) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1173,6 +1182,15 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
     HIP_TRY(hipHostGetDevicePointer(&dp, s->h_status, 0)); c.status_host = (int32_t*)dp; }
   c.scal = s->scal.p; c.status = s->status.p;
   c.own_node0 = t.own_node0; c.own_node1 = t.own_node1; c.own_agg0 = t.own_agg0; c.own_agg1 = t.own_agg1; c.tile0 = t.own_tile0; c.dist = 0;
+  c.wl_run_blocks = t.wl_run_blocks;
+  // Pre-reduced sums for the coarse kernels (red_i / red_a / red_b).  Large meshes: an aggregate has thousands of tile slots,
+  // and summing them inside every coarse workgroup (and inside every workgroup of k_minv_apply) costs more than one
+  // k_dist_reduce launch per half-iteration (refine 2, before: k_coarse_a 92 us, k_minv_apply 5.5 ms per call).  Partitioned handles
+  // use the same buffers for their all-reduced sums.
+  HIP_TRY(s->red_i.alloc(s->ncoarse)); HIP_TRY(s->red_a.alloc(2 + 3 * (size_t)s->ncoarse)); HIP_TRY(s->red_b.alloc(4 + (size_t)s->ncoarse));
+  c.red_i = s->red_i.p; c.red_a = s->red_a.p; c.red_b = s->red_b.p;
+  s->prereduce = !part && mesh->dim == 3 && t.tile_slots > 128;
+  if (s->prereduce) c.dist = 1;
   if (part) {
     s->partitioned = true; s->part_rank = part->rank; s->part_size = part->size;
     std::vector<int32_t> sn, rn;
@@ -1196,10 +1214,9 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
     HIP_TRY(s->send_nodes.upload(sn)); HIP_TRY(s->recv_nodes.upload(rn));
     const size_t wmax = (size_t)nf * nf;   // widest exchange: the inverse diagonal blocks of the ghost nodes
     HIP_TRY(s->sendbuf.alloc(std::max<size_t>(1, sn.size() * wmax))); HIP_TRY(s->recvbuf.alloc(std::max<size_t>(1, rn.size() * wmax)));
-    HIP_TRY(s->red_i.alloc(s->ncoarse)); HIP_TRY(s->red_a.alloc(2 + 3 * (size_t)s->ncoarse)); HIP_TRY(s->red_b.alloc(4 + (size_t)s->ncoarse));
     HIP_TRY(s->red_norm.alloc(8));
     HIP_TRY(hipHostMalloc((void**)&s->h_red, 8 * sizeof(double)));
-    c.dist = 1; c.red_i = s->red_i.p; c.red_a = s->red_a.p; c.red_b = s->red_b.p;
+    c.dist = 1;
   }
   rc = rebuild_boundary(s.get()); if (rc) return rc;
   rc = build_tridiagonal(s.get()); if (rc) return rc;

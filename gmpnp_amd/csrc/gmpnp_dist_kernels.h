@@ -27,28 +27,36 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nve
   dst.p[v][(size_t)nodes[k] * width + f] = buf[i];
 }
 
-// One wave per output value: a fixed-order sum of per-tile scalar partials or of per-slot restriction partials.
+// One WORKGROUP per output value: a fixed-order sum of per-tile scalar partials or of per-slot restriction partials (a
+// twice-refined mesh has 28,000 tiles and 3,500 slots per aggregate: one wave per output took 179 us per launch there).
 //   phase 0 (start of a solve)  out[d]                = sum_slot cpart_v[1][slot][d]                 (P^T r_0, left by k_krylov_init)
 //   phase 1 (after half A)      out[0..1]             = sum_tile part_a, part_rr ; out[2 + w n + d] = sum_slot (v, r, p)[par]
 //   phase 2 (after half B)      out[0..3]             = sum_tile part_b[m]       ; out[4 + d]       = sum_slot cpart_t
 //   phase 3 (end of a solve)    out[d]                = sum_slot cpart_v[0][slot][d]                 (P^T y, left by k_restrict)
 __global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int par, double* __restrict__ out) {
-  const int n = c.ncoarse, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  __shared__ double lds[4];
+  const int n = c.ncoarse, o = blockIdx.x, t = threadIdx.x;
   const int nscal = phase == 1 ? 2 : (phase == 2 ? 4 : 0);
-  const int nvecs = phase == 1 ? 3 : 1;
-  if (wave >= nscal + nvecs * n) return;
-  double acc = 0.0;
-  if (wave < nscal) {
-    const double* p = phase == 1 ? (wave == 0 ? c.part_a : c.part_rr) : c.part_b + (size_t)wave * c.ntiles;
-    for (int i = lane; i < c.ntiles; i += 64) acc += p[i];
+  const double* p; int count, stride;
+  if (o < nscal) {
+    p = phase == 1 ? (o == 0 ? c.part_a : c.part_rr) : c.part_b + (size_t)o * c.ntiles;
+    count = c.ntiles; stride = 1;
   } else {
-    const int q = wave - nscal, w = q / n, d = q - w * n;
-    const double* p = phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
-                      : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par]);
-    for (int sl = lane; sl < c.tile_slots; sl += 64) acc += p[(size_t)sl * n + d];
+    const int q = o - nscal, w = q / n, d = q - w * n;
+    p = (phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
+         : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par])) + d;
+    count = c.tile_slots; stride = n;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) out[wave] = acc;
+  double v[1] = {0.0};
+  for (int i0 = t; i0 < count; i0 += 8 * 256) {   // eight independent requests per thread and trip
+    double w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w8[u] = p[(size_t)min(i0 + u * 256, count - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[0] += (i0 + u * 256 < count) ? w8[u] : 0.0;
+  }
+  block_sum<1>(v, lds);
+  if (t == 0) out[o] = v[0];
 }
 
 // ||b||^2 of the owned rows (k_res_gather's per-workgroup partials) and the four status bits, as doubles for the all-reduce

@@ -215,7 +215,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
   for (gmpnp_solver* s : g->dom) {
     s->c.use_coarse = use_coarse;
     hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, (const double*)nullptr, init, s->cpart_v1.p);
-    if (use_coarse) hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for(n * kWave, 256)), dim3(256), 0, s->stream, s->c, 0, 0, s->red_i.p);
+    if (use_coarse) hipLaunchKernelGGL(k_dist_reduce, dim3(n), dim3(256), 0, s->stream, s->c, 0, 0, s->red_i.p);
   }
   HIP_TRY(hipGetLastError());
   int rc;
@@ -229,7 +229,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     for (gmpnp_solver* s : g->dom) {
       hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for((2 + 3 * n) * kWave, 256)), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(2 + 3 * n), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p);
     }
     int r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_a.p; }, 2 + 3 * n); if (r) return r;
     r = group_exchange(g, NF, 3, [par](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kr.p; w.p[1] = s->c.kv[par]; w.p[2] = s->c.kp[par]; return w; });
@@ -237,7 +237,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     for (gmpnp_solver* s : g->dom) {
       hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for((4 + n) * kWave, 256)), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(4 + n), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p);
     }
     r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_b.p; }, 4 + n); if (r) return r;
     r = group_exchange(g, NF, 2, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->ks.p; w.p[1] = s->kt.p; return w; });
@@ -282,7 +282,7 @@ int group_update(gmpnp_group* g, int mode, double omega, bool add_to_start) {
   if (use_coarse) {
     for (gmpnp_solver* s : g->dom) {
       hipLaunchKernelGGL((k_restrict<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, (const double*)s->ky.p, s->cpart_v0.p);
-      hipLaunchKernelGGL(k_dist_reduce, dim3(grid_for(n * kWave, 256)), dim3(256), 0, s->stream, s->c, 3, 0, s->red_i.p);
+      hipLaunchKernelGGL(k_dist_reduce, dim3(n), dim3(256), 0, s->stream, s->c, 3, 0, s->red_i.p);
     }
     int rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_i.p; }, n); if (rc) return rc;
   }

@@ -167,7 +167,9 @@ struct Ctx {
   int32_t own_node0, own_node1;   // owned nodes (internal order); [0, nv) for an unpartitioned handle
   int32_t own_agg0, own_agg1;     // aggregates made of owned nodes
   int32_t tile0;                  // first owned tile: the Krylov workgroups run tiles tile0 + blockIdx.x
-  int32_t dist;                   // 1 = partitioned: the coarse kernels read all-reduced sums from `red` instead of tile partials
+  int32_t dist;                   // 1 = the coarse kernels read pre-reduced sums (red_i/a/b) instead of tile partials: partitioned
+                                  //     solve (all-reduced over the ranks) and large unpartitioned meshes (k_dist_reduce per launch)
+  int32_t wl_run_blocks;          // workgroups per run of the gather work list
   double* red_i;                  // [ncoarse]          P^T r_0                                  (all-reduced over the ranks)
   double* red_a;                  // [2 + 3 ncoarse]    (rhat,v) ||r||^2 | P^T v | P^T r | P^T p
   double* red_b;                  // [4 + ncoarse]      (t,s) (t,t) (rhat,s) (rhat,t) | P^T t
@@ -195,6 +197,7 @@ struct Topology {
   std::vector<TileRec> tile_rec;
   int col_stride = 0;
   int ntiles = 0, tile_slots = 0;
+  int wl_run_blocks = 0;                  // workgroups per run of the gather work list (wl_slice / wl_kpos)
   int own_node0 = 0, own_node1 = 0;       // internal node range this handle owns (partitioned solve; everything otherwise)
   int own_agg0 = 0, own_agg1 = 0;         // aggregates made of owned nodes
   int own_tile0 = 0, own_ntiles = 0;      // their tiles (contiguous)

@@ -476,11 +476,11 @@ __global__ __launch_bounds__(kVecBlock) void k_res_gather(const Ctx c) {
 // XCDs round robin): the element records around a slice's nodes are then shared through that XCD's L2 by the ~15 waves
 // of the slice and by the neighbouring slices, instead of being fetched by every XCD.
 constexpr int kXcds = 8;
-// wave index into the work list: the list is eight equal runs (gmpnp_topology.cpp), workgroup b works in run b % 8
+// wave index into the work list: equal runs, a multiple of 8 of them (gmpnp_topology.cpp); XCD x takes runs x, x + 8, ...
 __device__ __forceinline__ int xcd_run_wave(const Ctx& c) {
-  const int per = (int)gridDim.x / kXcds;   // workgroups per run (the grid is 8 * per)
-  const int blk = ((int)blockIdx.x % kXcds) * per + (int)blockIdx.x / kXcds;
-  return (blk * kVecBlock + (int)threadIdx.x) >> 6;
+  const int x = (int)blockIdx.x % kXcds, j = (int)blockIdx.x / kXcds;          // XCD, position in that XCD's queue
+  const int run = x + kXcds * (j / c.wl_run_blocks), off = j - (j / c.wl_run_blocks) * c.wl_run_blocks;
+  return ((run * c.wl_run_blocks + off) * kVecBlock + (int)threadIdx.x) >> 6;
 }
 template <int DIM, int NF>
 __global__ __launch_bounds__(kVecBlock) void k_jac_gather(const Ctx c) {

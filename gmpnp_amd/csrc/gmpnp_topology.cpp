@@ -237,11 +237,13 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
             t.tile_aggs[(size_t)tl * kTileAggs + t.tile_nagg[tl]++] = g;
           }
         }
-  // Gather work list: one wave per (slice, block position).  Eight runs, one per XCD (k_jac_gather / k_scale_columns map
-  // workgroup b to run b % 8): a run holds a contiguous eighth of the slices, so the element records around those nodes are
-  // shared through ONE XCD's L2, and inside a run the heaviest positions (diagonal blocks: most element contributions) come
+  // Gather work list: one wave per (slice, block position).  The list is cut into runs of at most 80 contiguous slices, a
+  // multiple of 8 of them; XCD x (= workgroup index mod 8) works through runs x, x + 8, ... one after the other
+  // (k_jac_gather / k_scale_columns: xcd_run_wave), so the element records around a run's nodes are shared through ONE
+  // XCD's L2 while they are hot, and inside a run the heaviest positions (diagonal blocks: most element contributions) come
   // first.  Runs are padded to equal length with (-1, 0) entries (a wave that reads slice -1 exits).
-  { constexpr int kRuns = 8, kWavesPerBlock = kVecBlock / kWave;
+  { const int kRuns = 8 * std::max(1, (t.nslices + 639) / 640);
+    constexpr int kWavesPerBlock = kVecBlock / kWave;
     std::vector<std::vector<std::pair<int, int>>> runs(kRuns);
     size_t longest = 0;
     for (int g = 0; g < kRuns; ++g) {
@@ -254,6 +256,7 @@ static std::string build_pass(const gmpnp_mesh_t& m, const int32_t* perm_in, int
       longest = std::max(longest, runs[g].size());
     }
     longest = ((longest + kWavesPerBlock - 1) / kWavesPerBlock) * kWavesPerBlock;
+    t.wl_run_blocks = (int)(longest / kWavesPerBlock);
     for (int g = 0; g < kRuns; ++g)
       for (size_t q = 0; q < longest; ++q) {
         const bool on = q < runs[g].size();

@@ -504,7 +504,8 @@ class PartitionedSolver:
                     dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
                     t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=dev)
                     tdist.broadcast(t, src=0)
-                    idbuf = create_string_buffer(bytes(t.cpu().tolist()), backend.COMM_ID_BYTES)
+                    idbuf = create_string_buffer(backend.COMM_ID_BYTES)
+                    idbuf.raw = bytes(t.cpu().tolist())
                 elif nparts == 1:
                     self._check(self.lib.gmpnp_comm_unique_id(idbuf))
                 else:

@@ -128,7 +128,7 @@ typedef struct {
   double residuals[GMPNP_MAX_NEWTON_HISTORY]; /* ||b||_2 before iteration 0 and after each update */
   int32_t krylov_per_iteration[GMPNP_MAX_NEWTON_HISTORY];
   double ms_assemble, ms_setup, ms_krylov, ms_total; /* ms_total: host wall clock of the solve; the three phases are
-                                                        device times (hipEvents), filled when GMPNP_PHASE_TIMING=1 only */
+                                                        device times (hipEvents), filled with gmpnp_options_t.phase_timing only */
   int32_t direct_solves;        /* Newton iterations whose system the block-banded LU solved (mode 3 or fallback) */
   int32_t pad_;
 } gmpnp_newton_stats_t;
@@ -213,7 +213,7 @@ int64_t gmpnp_n_blocks(const gmpnp_solver* s);   /* node blocks of the BSR Jacob
 int64_t gmpnp_jacobian_nnz(const gmpnp_solver* s); /* n_blocks * n_fields^2 */
 int32_t gmpnp_n_aggregates(const gmpnp_solver* s);
 /* Kernel launches per BiCGStab iteration of the 3D solver: 4 (coarse, tile, coarse, tile) or 2 (the coarse workgroups
- * ride inside the tile launches; chosen when all workgroups of a launch are resident at once, GMPNP_FUSED_HALF=0/1
+ * ride inside the tile launches; chosen when the occupancy query proves all workgroups of a launch resident at once; gmpnp_options_t.launch_form
  * overrides). Diagnostics for the bench; no reference counterpart. */
 int32_t gmpnp_krylov_launches_per_iteration(const gmpnp_solver* s);
 

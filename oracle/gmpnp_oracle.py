@@ -16,15 +16,18 @@ What it restates (NumPy/SciPy, fp64), with the reference lines each function fol
 
 PARITY STATUS: the arithmetic of the reference lives in FEniCS 2019.1.0 / PETSc 3.12.3 / MUMPS 5.2.1 /
 UMFPACK (environment.yml:21-27,78,86,110), none of which exists in /root/reference or is installed
-or installable here, and the reference has no tests.  The oracle is pinned by (tests/test_oracle_*.py):
-finite-difference Jacobians, sympy-free closed-form element integrals vs. brute-force high-order
-quadrature, the mesh-independent steric-Boltzmann equilibrium behind 1D/Stern_CO2ER.py:66-68
-(recorded eps_rel_OHP values), the recorded OHP FIELD of the same file reproduced end to end (time loop +
-consistent-mass projection: 98.4 % of the recorded value after 40 steps and rising, 99.4-99.9 % after 160 steps at
-the four voltages run; the GPU driver lands within 0.1-0.6 % after 300 steps at all five), the wall-area check of
-3D/mesh_tests.py:80-85, and the L4 scalars.  Those two recorded quantities are the reference's only stored outputs.  The quadrature of the rational steric term follows FIAT's
-default degree-3 (F) / degree-4 (J) schemes restated from memory of the published FIAT sources:
-**parity unpinned** for that term (see gmpnp_amd/model.py::Quadrature).
+or installable here, and the reference has no tests.  What pins this oracle:
+* 1D MPNP path — PINNED on the only hot-path outputs the reference stores (1D/Stern_CO2ER.py:66-68, field_OHP and
+  eps_rel_OHP at five voltages): the GPU product, which reproduces this oracle's goldens step for step, run over the
+  reference's 20,000-solve staged schedule lands on the recorded digits to 4e-13 ... 1.5e-10 at four voltages
+  (profiles/r02/stern_schedule.json, tests/test_gpu_parity.py::test_staged_schedule_reproduces_the_recorded_digits); the
+  oracle itself follows the same trajectory (tests/test_oracle_pins.py; 20,000 direct solves are out of its reach).
+* 3D path — **parity unpinned** by reference-held numbers (there are none).  tests/test_literal_forms.py evaluates the
+  published 3D/1D integrands and parameter formulas literally (no Model tables) against element_residual_jacobian /
+  facet_terms; finite-difference Jacobians, closed-form element integrals vs brute-force quadrature, the steric-Boltzmann
+  equilibrium, the wall-area check of 3D/mesh_tests.py:80-85 and the L4 scalars are in tests/test_oracle*.py.  The
+  quadrature points of the rational steric term on tetrahedra follow FIAT's default degree-3 (F) / degree-4 (J) schemes
+  restated from memory of the published FIAT sources (gmpnp_amd/model.py::Quadrature): that ingredient is unpinned.
 """
 from __future__ import annotations
 

@@ -881,6 +881,26 @@ def test_config3_geometry_on_four_partitions(gpu_lib):
     assert relerr(out[1][1].ravel(), out[0][1].ravel()) < 1e-8
 
 
+def test_bench_partitioned_code_path_at_world_size_one(gpu_lib):
+    """Everything `bench.py --gpus N` does for N > 1 — torch.distributed process group, the RCCL id made by rank 0 and
+    broadcast through it, the communicator inside the library, PoreRun(partition=(N, rank)) with its per-step gather and
+    Dirichlet update, warm-up / reset / timed steps, the output line — run with ONE rank (`--force-partitioned`), which is
+    all a single-GPU box can host.  The one-partition run must count the Newton iterations of the single-GPU solver."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_PORT="29631")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                        "--force-partitioned"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    reh = out["partitioned_rehearsal"]
+    assert "error" not in reh, reh
+    assert reh["newton_iterations"] == out["config"]["newton_iterations"] and reh["value"] > 0
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+
+
 def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
     """The RCCL transport itself (librccl.so loaded by the library, communicator from gmpnp_comm_unique_id /
     gmpnp_comm_create, ncclAllReduce on the solver's stream) on the one rank a single-GPU box allows."""

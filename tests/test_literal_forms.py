@@ -340,3 +340,27 @@ def test_controller_updates_the_point_fluxes_like_the_reference():
         c = EdlConstants(L_n=10e-6, voltage_multiplier=-2.5, H2_FE=0.4, current_H_frac=frac)
         JH, JOH = ep.ohp_fluxes(frac)
         assert np.isclose(JH, c.J_point["H"], rtol=1e-13) and np.isclose(JOH, c.J_point["OH"], rtol=1e-13)
+
+
+def test_sechenov_feedback_is_the_published_formula():
+    """The per-step host feedback of the 3D loop (3D:70-93 CO2_conc, 3D:817-835): Henry's constant ln K_H = 93.4517 (100/T)
+    - 60.2409 + 23.3585 ln(T/100), h_CO2 = h0 + hT (T - 298.15), s = sum_ion (h_ion + h_CO2) c_ion / 1000 over OH, HCO3, CO32,
+    cation with c_ion = median(u_ion) bulk_ion, C = f_CO2 K_H 1000 10^-s; the new bc4 value is C / bulk_CO2.  Recomputed here
+    from the YAML numbers, against PoreParameters.sechenov_co2_scaled (what PoreRun.step and the oracle's time loop call)."""
+    import math
+    for kw in PORE_CASES:
+        c = PoreConstants(**kw)
+        pp = pore_parameters(**kw)
+        d = _load("parameters_pore.yaml")
+        T = d["sys_params"]["T"]
+        hs = d["sechonov_const"]
+        y_CO2, press = kw.get("y_CO2", 0.95), kw.get("press_gas", 1.0)
+        lnK = 93.4517 * (100 / T) - 60.2409 + 23.3585 * math.log(T / 100)
+        h_CO2 = hs["h_CO2_0"] + hs["h_CO2_T"] * (T - 298.15)
+        rng = np.random.default_rng(3)
+        for _ in range(5):
+            med = dict(zip(("OH", "HCO3", "CO32", c.cat), rng.uniform(0.2, 3.0, 4)))
+            s = sum((hs["h_ion_" + ion] + h_CO2) * (med[ion] * c.bulk[ion] / 1000) for ion in med)
+            want = (y_CO2 * press) * math.exp(lnK) * 1000 * 10 ** (-s) / c.bulk["CO2"]
+            got = pp.sechenov_co2_scaled(med["OH"], med["HCO3"], med["CO32"], med[c.cat])
+            assert abs(got / want - 1.0) < 1e-13

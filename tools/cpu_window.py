@@ -15,7 +15,8 @@ ap.add_argument("--threads", type=int, default=1, help="BLAS/OpenMP threads (0 =
 ap.add_argument("--out", type=str, default=None)
 ap.add_argument("--first", type=int, default=0, help="first time step of this call (a gpurun call is limited to 20 min: the window is timed in two halves)")
 ap.add_argument("--load", type=str, default=None, help="checkpoint (npz: u, un, co2, accumulated timings) of the previous half")
-ap.add_argument("--save", type=str, default=None)
+ap.add_argument("--save", type=str, default=None, help="checkpoint written after EVERY step")
+ap.add_argument("--time-budget", type=float, default=0.0, help="stop cleanly after this many seconds of THIS call (0 = run to --steps)")
 a = ap.parse_args()
 nthreads = a.threads if a.threads > 0 else (os.cpu_count() or 1)
 for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -50,10 +51,13 @@ for n in range(a.first, a.steps):
     prob.bc_dofs, prob.bc_vals = pore_dirichlet(pp, bnd, co2)
     un = u.copy()
     its.append(st.iterations); t_asm += st.t_assemble; t_lu += st.t_linear
-    print("step %d: %d Newton iterations, %.1f s so far" % (n, st.iterations, time.perf_counter() - t0), flush=True)
+    wall = wall_before + time.perf_counter() - t0
+    print("step %d: %d Newton iterations, %.1f s so far" % (n, st.iterations, wall), flush=True)
+    if a.save:
+        np.savez(a.save, u=u, un=un, co2=co2, its=np.array(its), t_asm=t_asm, t_lu=t_lu, wall=wall)
+    if a.time_budget > 0 and time.perf_counter() - t0 > a.time_budget:
+        break
 wall = wall_before + time.perf_counter() - t0
-if a.save:
-    np.savez(a.save, u=u, un=un, co2=co2, its=np.array(its), t_asm=t_asm, t_lu=t_lu, wall=wall)
 out = {"workload": "3D MPNP_CO2ER_pore L_50_R_5, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0" % (a.steps - 1),
        "kind": "port (CPU oracle: NumPy assembly + SciPy SuperLU; FEniCS/MUMPS not installable)",
        "note": "solve phase only (mesh ingest and the one-off scatter pattern excluded); timed in calls of <= 20 min, state carried over",

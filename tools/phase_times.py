@@ -1,4 +1,4 @@
-"""Development probe: phase timestamps inside k_bicg_a (needs a library built with -DGMPNP_TIMING, passed via GMPNP_LIB)."""
+"""Development probe: phase timestamps inside k_bicg_a (needs a library built with -DGMPNP_TIMING -DGMPNP_DEV_HOOKS, passed via GMPNP_LIB)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
