@@ -143,6 +143,7 @@ struct gmpnp_solver {
   hipEvent_t ev_poll[2] = {};
   // mesh partition (gmpnp_create_partition): halo plan in INTERNAL node ids, buffers of the fused exchanges
   bool partitioned = false; int part_rank = 0, part_size = 1;
+  bool matp = false;        // materialised vector form of the BiCGStab half-iterations (opts.vector_form; automatic above 768 MB of matrix)
   bool prereduce = false;   // unpartitioned, many tile slots per aggregate: k_dist_reduce feeds the coarse kernels (Ctx::dist)
   std::vector<int32_t> nb_rank, send_ptr, recv_ptr;   // neighbours; [n_neighbours + 1] offsets into the node lists
   DevBuf<int32_t> send_nodes, recv_nodes;
@@ -366,6 +367,19 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
     } else {
       if (ev) hipExtLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
       else hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
+    }
+  } else if (s->matp) {   // materialised vectors: coarse kernel, streaming vector update, tile kernel staging one vector
+    const dim3 vg(grid_for(s->ndof, 256));
+    if (WHICH == 0) {
+      hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL(k_vec_a, vg, dim3(256), 0, s->stream, s->c, k);
+      if (ev) hipExtLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
+      else hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    } else {
+      hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL(k_vec_b, vg, dim3(256), 0, s->stream, s->c, k);
+      if (ev) hipExtLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
+      else hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
     }
   } else if (WHICH == 0) {
     hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
@@ -1100,7 +1114,8 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
   HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
   const gmpnp_options_t& po = s->opts;
   if (po.launch_form != 0 && po.launch_form != 2 && po.launch_form != 4) return fail(GMPNP_ERR_INVALID, "launch_form must be 0, 2 or 4");
-  if (po.coarse_refresh < 0 || po.burst_iterations < 0 || po.warm_start < -1 || po.warm_start > 1 || !(po.band_lu_max_gb >= 0.0))
+  if (po.coarse_refresh < 0 || po.burst_iterations < 0 || po.warm_start < -1 || po.warm_start > 1 || !(po.band_lu_max_gb >= 0.0) ||
+      po.vector_form < 0 || po.vector_form > 2)
     return fail(GMPNP_ERR_INVALID, "option out of range");
   s->coarse_async = (po.coarse_refresh == 0 && !po.shared_device) ? 1 : 0;
   s->coarse_lag = po.coarse_refresh > 0 ? po.coarse_refresh : 3;
@@ -1152,6 +1167,15 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
       return fail(GMPNP_ERR_INVALID, buf);
     }
     s->fused_half = po.launch_form == 4 ? false : (resident && !po.shared_device && !s->prereduce);
+    // Vector form.  On-the-fly (the tile kernels recompute p / s at their column nodes from four / two vectors: one launch
+    // per half-iteration) wins while the operands are cache resident; materialised (k_vec_a / k_vec_b write p / s for all
+    // rows first, the tile kernels stage one vector) wins once the gathers cost memory bandwidth: matrix above 768 MB.
+    const double matrix_mb = (double)s->nb * nf * nf * sizeof(double) / 1e6;
+    s->matp = !part && mesh->dim == 3 && (po.vector_form == 1 || (po.vector_form == 0 && matrix_mb > 768.0));
+    if (s->matp) {
+      if (po.launch_form == 2) return fail(GMPNP_ERR_INVALID, "vector_form 1 (materialised) has its own launches: not with launch_form 2");
+      s->fused_half = false;
+    }
   }
   HIP_TRY(hipHostMalloc((void**)&s->h_part, 3 * std::max(s->n_resblocks, 1) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
   HIP_TRY(hipHostMalloc((void**)&s->h_status, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1539,12 +1563,16 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
                                                     (unsigned)(++s->fused_seq))); break;
       case 13: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_half_b<NF>), dim3(s->t.nagg + s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1,
                                                     (unsigned)(++s->fused_seq))); break;
+      case 14: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 15: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
+      case 16: hipLaunchKernelGGL(k_vec_a, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, 1); break;
+      case 17: hipLaunchKernelGGL(k_vec_b, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, 1); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
     return r;
   };
   if (kernel == 12 || kernel == 13) { HIP_TRY(hipMemset(s->ticket.p, 0, 16 * 66 * sizeof(uint32_t))); s->fused_seq = 0; }
-  if ((kernel >= 4 && kernel <= 7) || kernel == 12 || kernel == 13) {  // Krylov kernels: a live (not finished) solve state
+  if ((kernel >= 4 && kernel <= 7) || (kernel >= 12 && kernel <= 17)) {  // Krylov kernels: a live (not finished) solve state
     KrylovScalars z{}; z.rho[0] = z.rho[1] = 1.0; z.alpha = 1.0; z.omega = 1.0; z.beta = 0.5; z.tol = 0.0; z.max_iters = 1 << 30;
     HIP_TRY(hipMemcpy(s->scal.p, &z, sizeof z, hipMemcpyHostToDevice));
   }

@@ -1248,8 +1248,13 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
 }
 
 // ---- fused half-iterations ------------------------------------------------------------------------------------
-template <int NF, bool FUSED>
+// MAT ("materialised"): p_k (resp. s_k) was written for ALL rows by k_vec_a (k_vec_b) in front of this launch, together with
+// the own-row updates of y and r; the tile stages ONE vector at its column nodes instead of recomputing p from four (s from
+// two).  Pays where the operand gathers cost HBM / Infinity-Cache bandwidth (twice-refined meshes: a tile's four staged vectors
+// are as many bytes as its matrix slice), not on the reference meshes, where one more launch per half-iteration costs more.
+template <int NF, bool FUSED, bool MAT = false>
 __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int tile, const unsigned target) {
+  static_assert(!(FUSED && MAT), "the materialised form has its own launches");
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
@@ -1270,7 +1275,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   if (!FUSED) { omega = sc->omega; beta = sc->beta; }
   const double* __restrict__ po = c.kp[par ^ 1];
   const double* __restrict__ vo = c.kv[par ^ 1];
-  const double* __restrict__ sfirst = first ? c.kr : c.ks;  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
+  const double* __restrict__ sfirst = MAT ? c.kp[par] : (first ? c.kr : c.ks);  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
   // every global request of this launch, issued together
   // two independent chains: the tile record -> matrix values / local column indices, and the tile's column list
   // (fixed stride: addressable without the record) -> operands of the staged x entries
@@ -1293,12 +1298,15 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
-    st_s[u] = sfirst[idx]; st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx];  // k = 0: only st_s is used
+    st_s[u] = sfirst[idx];
+    if (MAT) { st_t[u] = 0.0; st_p[u] = 0.0; st_v[u] = 0.0; }
+    else { st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx]; }  // k = 0: only st_s is used
   }
   // own rows (the epilogue of wave 0 needs six vectors at its rows): wave q requests vector q and hands it over through
   // LDS, so that no load sits behind a branch and nobody holds six values
   const int own_r = rows.row;  // inactive lanes: row 0
-  const double* ownp = wv == 0 ? c.krhat : wv == 1 ? sfirst : wv == 2 ? c.kt : wv == 3 ? po : wv == 4 ? vo : c.ky;
+  const double* ownp = MAT ? (wv == 0 ? c.krhat : wv == 1 ? c.kr : c.kp[par])   // r_k and p_k are in place already
+                           : (wv == 0 ? c.krhat : wv == 1 ? sfirst : wv == 2 ? c.kt : wv == 3 ? po : wv == 4 ? vo : c.ky);
   const double own_q = ownp[own_r];
   { double keep = own_q + (FUSED ? 0.0 : tcs.a0 + tcs.a1);
 #pragma unroll
@@ -1322,7 +1330,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     if (q < nst) {
-      const double pj = first ? st_s[u] : (st_s[u] - omega * st_t[u]) + beta * (st_p[u] - omega * st_v[u]);
+      const double pj = (first || MAT) ? st_s[u] : (st_s[u] - omega * st_t[u]) + beta * (st_p[u] - omega * st_v[u]);
       xs[q] = pj + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
     }
   }
@@ -1330,7 +1338,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    const double pj = first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
+    const double pj = MAT ? c.kp[par][idx] : first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
     xs[q] = pj + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
@@ -1345,14 +1353,17 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     if (rows.active) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
-      if (first) { rn = own_s; pn = rn; }
+      if (MAT) { rn = own_s; pn = own_t; }   // own[1] = r_k, own[2] = p_k (k_vec_a)
       else {
-        c.ky[own_r] = own_y + alpha * own_p + omega * own_s;
-        rn = own_s - omega * own_t;
-        c.kr[own_r] = rn;
-        pn = rn + beta * (own_p - omega * own_v);
+        if (first) { rn = own_s; pn = rn; }
+        else {
+          c.ky[own_r] = own_y + alpha * own_p + omega * own_s;
+          rn = own_s - omega * own_t;
+          c.kr[own_r] = rn;
+          pn = rn + beta * (own_p - omega * own_v);
+        }
+        c.kp[par][own_r] = pn;
       }
-      c.kp[par][own_r] = pn;
       c.kv[par][own_r] = tot;
     }
     outv[0][sl][lane] = tot; outv[1][sl][lane] = rn; outv[2][sl][lane] = pn;
@@ -1378,8 +1389,9 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
 #endif
 }
 
-template <int NF, bool FUSED>
+template <int NF, bool FUSED, bool MAT = false>
 __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int tile, const unsigned target) {
+  static_assert(!(FUSED && MAT), "the materialised form has its own launches");
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[kSlicesPerTile][64];
@@ -1415,10 +1427,10 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
-    st_r[u] = c.kr[idx]; st_v[u] = vn[idx];
+    st_r[u] = MAT ? c.ks[idx] : c.kr[idx]; st_v[u] = MAT ? 0.0 : vn[idx];   // MAT: s_k was written by k_vec_b
   }
   const int own_r = rows.row;  // inactive lanes: row 0
-  const double* ownp = wv == 0 ? c.krhat : wv == 1 ? c.kr : vn;  // wave q requests own-row vector q (see k_bicg_a)
+  const double* ownp = wv == 0 ? c.krhat : wv == 1 ? (MAT ? c.ks : c.kr) : vn;  // wave q requests own-row vector q (see k_bicg_a)
   const double own_q = ownp[own_r];
   { double keep = own_q + (FUSED ? 0.0 : tcs.a0 + tcs.a1);
 #pragma unroll
@@ -1445,13 +1457,13 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    if (q < nst) xs[q] = (st_r[u] - alpha * st_v[u]) + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
+    if (q < nst) xs[q] = (MAT ? st_r[u] : st_r[u] - alpha * st_v[u]) + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
   }
   if (wv < 3) own[wv][lane] = own_q;
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    xs[q] = (c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
+    xs[q] = (MAT ? c.ks[idx] : c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
   red[wv][lane] = rows.dot(c, xs);
@@ -1462,8 +1474,8 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     if (rows.active) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) tt += red[sl * NW + q][lane];
-      sv = own_r_ - alpha * own_v;
-      c.ks[own_r] = sv;
+      sv = MAT ? own_r_ : own_r_ - alpha * own_v;
+      if (!MAT) c.ks[own_r] = sv;
       c.kt[own_r] = tt;
     }
     outv[sl][lane] = tt;
@@ -1497,6 +1509,33 @@ template <int NF>
 __global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
+
+// Materialised form (large meshes): the vector recurrences run as their own streaming launches in front of the tile kernels.
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a_mat(const Ctx c, const int k) { bicg_a_body<NF, false, true>(c, k, c.tile0 + blockIdx.x, 0u); }
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b_mat(const Ctx c, const int k) { bicg_b_body<NF, false, true>(c, k, c.tile0 + blockIdx.x, 0u); }
+// y += alpha p_{k-1} + omega s ; r_k = s - omega t ; p_k = r_k + beta (p_{k-1} - omega v_{k-1})   (k = 0: p_0 = r_0), all rows
+__global__ __launch_bounds__(256) void k_vec_a(const Ctx c, const int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const KrylovScalars* sc = c.scal;
+  if (i >= c.ndof || sc->done) return;
+  const int par = k & 1;
+  if (k == 0) { c.kp[par][i] = c.kr[i]; return; }
+  const double alpha = sc->alpha, omega = sc->omega, beta = sc->beta;
+  const double s = c.ks[i], t = c.kt[i], po = c.kp[par ^ 1][i], vo = c.kv[par ^ 1][i];
+  c.ky[i] += alpha * po + omega * s;
+  const double rn = s - omega * t;
+  c.kr[i] = rn;
+  c.kp[par][i] = rn + beta * (po - omega * vo);
+}
+// s_k = r_k - alpha v_k, all rows (nothing to do once coarse_b(k) has seen the end of the solve)
+__global__ __launch_bounds__(256) void k_vec_b(const Ctx c, const int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const KrylovScalars* sc = c.scal;
+  if (i >= c.ndof || sc->done || sc->done_next) return;
+  c.ks[i] = c.kr[i] - sc->alpha * c.kv[k & 1][i];
+}
 
 // ... or two: the nagg coarse workgroups ride in front of the tile workgroups of the same launch.  A tile workgroup
 // requests everything that does not depend on the coarse result (indices, matrix slice, operand vectors), then waits

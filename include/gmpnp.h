@@ -164,7 +164,10 @@ typedef struct {
                              and one wait more per iteration) */
   int32_t no_direct_fallback; /* 1 = a 3D Krylov solve that does not converge is an error instead of a block-banded LU solve */
   int32_t warm_in_stream; /* 1 = the test of the predicted start runs in the main stream behind the set-up */
-  int32_t reserved_[3];   /* zero */
+  int32_t vector_form;    /* BiCGStab half-iterations: 2 = the tile kernels recompute p / s at their column nodes on the fly (one launch
+                             per half-iteration), 1 = streaming kernels write p / s for all rows first and the tile kernels stage
+                             one vector (wins when the gathers cost memory bandwidth), 0 = automatic (1 above 768 MB of matrix) */
+  int32_t reserved_[2];   /* zero */
   double band_lu_max_gb;  /* largest band storage the direct solver may allocate; 0 = 48 */
 } gmpnp_options_t;
 
@@ -307,7 +310,8 @@ int gmpnp_group_assign_previous(gmpnp_group* g);
  * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming
  * read of the matrix buffer with 2048 / 512 / 8192 workgroups (bandwidth probes), 12/13 = the two-launch form of the
- * half-iterations (coarse workgroups inside the tile launch). */
+ * half-iterations (coarse workgroups inside the tile launch), 14/15 = the tile kernels of the materialised vector form,
+ * 16/17 = its streaming vector updates. */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
 /* Fused BiCGStab half-iteration launches (k_bicg_a / k_bicg_b: SpMV + vector updates) sampled with HIP events since
  * the last call (opts.profile_every): count, mean microseconds between the two events of a bracket. */

@@ -671,6 +671,12 @@ def test_solver_variants_agree(gpu_lib):
     assert its_c == its and relerr(cold.ravel(), ref.ravel()) < 1e-8
     first_order, its_f, _ = _run_pore10(warm_start=1)
     assert its_f == its and relerr(first_order.ravel(), ref.ravel()) < 1e-8
+    # materialised vector form (automatic on meshes above 768 MB of matrix): p / s written for all rows by streaming
+    # kernels, the tile kernels stage one vector instead of four / two — the same recurrences in other launches
+    mat, its_m, launches_m = _run_pore10(vector_form=1)
+    assert launches_m == 4 and its_m == its and relerr(mat.ravel(), ref.ravel()) < 1e-8
+    with pytest.raises(gpu_lib.GmpnpError, match="vector_form 1"):
+        _run_pore10(vector_form=1, launch_form=2)
     # coarse operator rebuilt in the main stream every third iteration instead of on the side stream: another valid
     # preconditioner, same Newton path; and the side-stream scheme is deterministic (events order the two streams)
     sync3, its_s, _ = _run_pore10(coarse_refresh=3)

@@ -27,8 +27,9 @@ for lev in levels:
     alg = 648 * nb + 4 * nb + 4 * (nv + 1) + 16 * nd
     print("level %d: %d vertices, %d cells, %d dofs, %.1f MB Jacobian; setup %.1fs; newton %d its, krylov %s, %.3f s -> %.1f its/s"
           % (lev, nv, len(prob.cells), nd, 648e-6 * nb, t1 - t0, st["iterations"], st["krylov_per_iteration"], t3 - t2, st["iterations"] / (t3 - t2)), flush=True)
-    for k, name in ((0, "spmv_plain"), (4, "bicg_a"), (5, "bicg_b"), (6, "coarse_a"), (7, "coarse_b"), (1, "element"), (2, "jac_gather"), (3, "res_gather")):
+    for k, name in ((0, "spmv_plain"), (4, "bicg_a"), (5, "bicg_b"), (14, "bicg_a_mat"), (15, "bicg_b_mat"), (16, "vec_a"), (17, "vec_b"), (6, "coarse_a"),
+                    (7, "coarse_b"), (1, "element"), (2, "jac_gather"), (3, "res_gather")):
         us = dev.time_kernel(k, 50)
-        extra = "  %.0f GB/s algorithmic" % (alg / us / 1e3) if k in (0, 4, 5) else ""
+        extra = "  %.0f GB/s algorithmic" % (alg / us / 1e3) if k in (0, 4, 5, 14, 15) else ""
         print("   %-12s %9.2f us%s" % (name, us, extra), flush=True)
     dev.close()
