@@ -250,6 +250,12 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
         else:
             kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
+        # what an EMPTY start/stop event pair measures on this stream: the sampled durations carry that much dispatch /
+        # completion latency on top of the kernel's own time (rocprofv3's kernel trace of the same command is the check)
+        try:
+            ev_overhead = dev.event_overhead(200)
+        except Exception:  # noqa: BLE001
+            ev_overhead = None
         # memory-side bytes per launch from the committed PMC passes; only valid for the build they were measured on
         traffic, traffic_note = None, "no PMC file"
         pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
@@ -276,6 +282,8 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
+                         "empty_event_pair_us": ev_overhead,
+                         "achieved_minus_event_overhead": (alg_bytes / ((mean_us - ev_overhead) * 1e-6) / 1e9) if ev_overhead and mean_us > ev_overhead else None,
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
                          "launches_per_krylov_iteration": launches},
         }
