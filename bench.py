@@ -211,21 +211,29 @@ def main():
         wd = threading.Timer(a.partition_timeout, bail)
         wd.daemon = True
         wd.start()
-        try:
-            if backend != "nccl":
-                raise RuntimeError("the partitioned solve needs one GPU per rank (RCCL); backend %r is a rehearsal of the replicas only" % backend)
-            prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local}, **common)
+        # transports in order of preference: RCCL inside the library (one GPU per rank); the library's host-staged transport
+        # over torch.distributed/gloo (ranks sharing a card in a rehearsal, or RCCL unavailable): same algorithm, PCIe per collective
+        errors = []
+        for transport in (["rccl"] if backend == "nccl" else []) + ["host"]:
             try:
-                pdt = timed(prun)
-                pits, pkry = float(sum(prun.newton_its)), float(prun.sys.krylov_iterations)
-                tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                part = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
-                        "ms_per_step": 1e3 * float(tt[0]) / a.steps}
-            finally:
-                prun.sys.close()
-        except Exception as e:  # noqa: BLE001
-            part = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport}, **common)
+                try:
+                    pdt = timed(prun)
+                    pits, pkry = float(sum(prun.newton_its)), float(prun.sys.krylov_iterations)
+                    tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    part = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
+                            "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport}
+                finally:
+                    prun.sys.close()
+                break
+            except Exception as e:  # noqa: BLE001
+                errors.append("%s transport: %s: %s" % (transport, type(e).__name__, str(e)[:300]))
+                # every rank must take the same branch: an error on one rank only would leave the others in a collective,
+                # where the watchdog ends the phase
+                part = {"error": "; ".join(errors)}
+        if part is not None and errors and "value" in part:
+            part["earlier_errors"] = errors
         wd.cancel()
 
     if rank == 0:
@@ -297,10 +305,12 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
                 # the headline at N > 1: ONE problem on N GPUs (strong scaling; Newton iterations counted once)
                 out.update(value=part["value"], ms_per_step=part["ms_per_step"], scaling="strong")
                 out["config"].update(newton_iterations=part["newton_iterations"], krylov_iterations=part["krylov_iterations"],
-                                     parallelism="ONE problem, %d z-slab mesh partitions, one per GPU: RCCL ghost-row exchange + one fused "
-                                                 "all-reduce per BiCGStab half-iteration, global coarse space (gmpnp_group_newton_solve)" % world)
+                                     parallelism="ONE problem, %d z-slab mesh partitions, one per rank: ghost-row exchange + one fused all-reduce per "
+                                                 "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
+                                                 % (world, "RCCL on the solver's stream" if part.get("transport") == "rccl" else "host-staged transport over torch.distributed"))
                 out["roofline"]["note"] = "kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)"
                 out["replicas"] = replicas
+                out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "earlier_errors") if k in part}
             else:
                 out["replicas"] = replicas
                 out["partitioned"] = part or {"error": "not run (--replicas-only)"}

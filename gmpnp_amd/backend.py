@@ -29,7 +29,7 @@ EXPORTS = [
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
     "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
-    "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create",
+    "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create", "gmpnp_group_create_hosted",
     "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
@@ -80,6 +80,16 @@ class CPartition(ctypes.Structure):
                 ("n_neighbours", c_int32), ("neighbour_rank", POINTER(c_int32)),
                 ("send_ptr", POINTER(c_int32)), ("send_vertices", POINTER(c_int32)),
                 ("recv_ptr", POINTER(c_int32)), ("recv_vertices", POINTER(c_int32))]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, POINTER(c_double), c_int32)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_int32, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_double),
+                               POINTER(c_int64), POINTER(c_int64), POINTER(c_double))
+
+
+class CHostTransport(ctypes.Structure):
+    """gmpnp_host_transport_t (include/gmpnp.h)."""
+    _fields_ = [("rank", c_int32), ("size", c_int32), ("allreduce", ALLREDUCE_FN), ("exchange", EXCHANGE_FN), ("user", c_void_p)]
 
 
 class GmpnpError(RuntimeError):
@@ -145,6 +155,7 @@ def load_library(path: str = None):
     lib.gmpnp_comm_selftest.argtypes = [c_void_p, c_int32, POINTER(c_double)]
     lib.gmpnp_comm_destroy.restype = None
     lib.gmpnp_group_create.argtypes = [c_int32, POINTER(c_void_p), c_void_p, POINTER(c_void_p)]
+    lib.gmpnp_group_create_hosted.argtypes = [c_void_p, POINTER(CHostTransport), POINTER(c_void_p)]
     lib.gmpnp_group_destroy.argtypes = [c_void_p]
     lib.gmpnp_group_destroy.restype = None
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]

@@ -86,6 +86,10 @@ struct gmpnp_group {
   std::vector<hipStream_t> own_stream;  // in-process mode: the handles' own streams, given back at destroy
   std::vector<std::vector<int>> peer_slot;  // in-process mode: peer_slot[d][j] = index of d in the neighbour list of d's neighbour j
   int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
+  // caller-provided transport (gmpnp_group_create_hosted): collectives staged through pinned host memory
+  bool hosted = false; gmpnp_host_transport_t host{};
+  double* h_stage = nullptr; size_t h_stage_n = 0;   // pinned: [send | recv] or the all-reduce buffer
+  std::vector<int64_t> off_s, cnt_s, off_r, cnt_r;
 };
 
 namespace {
@@ -93,6 +97,16 @@ namespace {
 // ---- collectives over the local handles ------------------------------------------------------------------------------------
 template <class F>
 int group_allreduce(gmpnp_group* g, F buf_of, int n) {
+  if (g->hosted) {
+    gmpnp_solver* s = g->dom[0];
+    if ((size_t)n > g->h_stage_n) return fail(GMPNP_ERR_INVALID, "hosted transport: staging buffer too small");
+    HIP_TRY(hipMemcpyAsync(g->h_stage, buf_of(s), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (g->host.allreduce(g->host.user, g->h_stage, n) != 0) return fail(GMPNP_ERR_HIP, "hosted transport: allreduce callback failed");
+    HIP_TRY(hipMemcpyAsync(buf_of(s), g->h_stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));   // the staging buffer is reused by the next collective
+    return GMPNP_OK;
+  }
   if (g->comm) {
     RcclApi* api = rccl_api(nullptr);
     gmpnp_solver* s = g->dom[0];
@@ -119,7 +133,26 @@ int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
   }
   HIP_TRY(hipGetLastError());
   const size_t per = (size_t)nvec * width;
-  if (g->comm) {
+  if (g->hosted) {
+    gmpnp_solver* s = g->dom[0];
+    const size_t nb = s->nb_rank.size();
+    if (nb) {
+      const size_t ns = (size_t)s->send_ptr.back() * per, nr = (size_t)s->recv_ptr.back() * per;
+      if (ns + nr > g->h_stage_n) return fail(GMPNP_ERR_INVALID, "hosted transport: staging buffer too small");
+      double* hs = g->h_stage; double* hr = g->h_stage + ns;
+      g->off_s.resize(nb); g->cnt_s.resize(nb); g->off_r.resize(nb); g->cnt_r.resize(nb);
+      for (size_t j = 0; j < nb; ++j) {
+        g->off_s[j] = (int64_t)s->send_ptr[j] * per; g->cnt_s[j] = (int64_t)(s->send_ptr[j + 1] - s->send_ptr[j]) * per;
+        g->off_r[j] = (int64_t)s->recv_ptr[j] * per; g->cnt_r[j] = (int64_t)(s->recv_ptr[j + 1] - s->recv_ptr[j]) * per;
+      }
+      HIP_TRY(hipMemcpyAsync(hs, s->sendbuf.p, ns * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (g->host.exchange(g->host.user, (int32_t)nb, s->nb_rank.data(), g->off_s.data(), g->cnt_s.data(), hs, g->off_r.data(), g->cnt_r.data(), hr) != 0)
+        return fail(GMPNP_ERR_HIP, "hosted transport: exchange callback failed");
+      HIP_TRY(hipMemcpyAsync(s->recvbuf.p, hr, nr * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+  } else if (g->comm) {
     RcclApi* api = rccl_api(nullptr);
     gmpnp_solver* s = g->dom[0];
     if (!s->nb_rank.empty()) {
@@ -480,8 +513,25 @@ int gmpnp_group_create(int32_t n_local, gmpnp_solver* const* handles, gmpnp_comm
   return GMPNP_OK;
 }
 
+int gmpnp_group_create_hosted(gmpnp_solver* handle, const gmpnp_host_transport_t* t, gmpnp_group** out) {
+  if (!handle || !t || !out || !t->allreduce || !t->exchange) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  *out = nullptr;
+  if (!handle->partitioned) return fail(GMPNP_ERR_INVALID, "group members must come from gmpnp_create_partition");
+  if (t->size != handle->part_size || t->rank != handle->part_rank) return fail(GMPNP_ERR_INVALID, "transport rank/size differ from the partition's");
+  std::unique_ptr<gmpnp_group> g(new gmpnp_group);
+  g->dom.push_back(handle);
+  g->hosted = true; g->host = *t;
+  const size_t n = (size_t)handle->ncoarse;
+  g->h_stage_n = std::max<size_t>({handle->sendbuf.n + handle->recvbuf.n, n * n, 2 + 3 * n, (size_t)64});
+  HIP_TRY(hipSetDevice(handle->opts.device_id));
+  HIP_TRY(hipHostMalloc((void**)&g->h_stage, g->h_stage_n * sizeof(double)));
+  *out = g.release();
+  return GMPNP_OK;
+}
+
 void gmpnp_group_destroy(gmpnp_group* g) {
   if (!g) return;
+  if (g->h_stage) (void)hipHostFree(g->h_stage);
   if (!g->dom.empty()) { (void)hipSetDevice(g->dom[0]->opts.device_id); (void)hipStreamSynchronize(g->dom[0]->stream); }
   for (size_t d = 1; d < g->own_stream.size(); ++d) if (g->own_stream[d]) g->dom[d]->stream = g->own_stream[d];
   delete g;

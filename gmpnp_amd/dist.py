@@ -479,7 +479,10 @@ class PartitionedSolver:
     The Krylov and Newton loops run in the library; Python only scatters / gathers states and per-step boundary values."""
 
     def __init__(self, prob: Problem, nparts: int, rank: int = None, device_id: int = 0, n_global_aggregates: int = None,
-                 use_torch_dist: bool = True, **device_kwargs):
+                 use_torch_dist: bool = True, transport: str = "rccl", **device_kwargs):
+        """``transport`` (one rank per process only): "rccl" — collectives inside the library over RCCL; "host" — the library
+        stages every collective through pinned host memory and calls back into ``torch.distributed`` (any backend, e.g.
+        gloo): for ranks that share one GPU (RCCL refuses that) and for machines without RCCL between the ranks."""
         from ctypes import byref, c_void_p, create_string_buffer
         from . import backend
         self.backend = backend
@@ -493,6 +496,11 @@ class PartitionedSolver:
             self.doms.append(dom)
             self.devs.append(backend.DeviceSolver(dom.problem, device_id=device_id, perm=perm, partition=part, **device_kwargs))
         self._comm = c_void_p()
+        self._group = c_void_p()
+        if rank is not None and transport == "host":
+            self._make_host_transport(rank, nparts)
+            self._check(self.lib.gmpnp_group_create_hosted(self.devs[0]._h, byref(self._host_transport), byref(self._group)))
+            return
         if rank is not None:
             idbuf = create_string_buffer(backend.COMM_ID_BYTES)
             if nparts > 1 or use_torch_dist:
@@ -514,12 +522,61 @@ class PartitionedSolver:
                 self._check(self.lib.gmpnp_comm_unique_id(idbuf))
             self._check(self.lib.gmpnp_comm_create(idbuf, rank, nparts, device_id, byref(self._comm)))
         handles = (c_void_p * len(self.devs))(*[d._h for d in self.devs])
-        self._group = c_void_p()
         self._check(self.lib.gmpnp_group_create(len(self.devs), handles, self._comm if rank is not None else None, byref(self._group)))
 
     def _check(self, code):
         if code != self.backend.OK:
             raise self.backend.GmpnpError(code, self.lib.gmpnp_last_error().decode())
+
+    def _make_host_transport(self, rank, nparts):
+        """The two callbacks of gmpnp_host_transport_t on torch.distributed (CPU tensors that alias the library's pinned
+        staging buffers: no copies on this side)."""
+        import torch
+        import torch.distributed as tdist
+        backend = self.backend
+        if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() == nparts):
+            raise RuntimeError("the host transport needs an initialised torch.distributed group of %d ranks" % nparts)
+
+        # host tensors need a CPU-capable backend: a gloo group next to an nccl default group
+        grp = tdist.new_group(backend="gloo") if tdist.get_backend() == "nccl" else None
+        self._host_group = grp
+
+        def view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+
+        def allreduce(_user, buf, n):
+            try:
+                tdist.all_reduce(view(buf, n), group=grp)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def exchange(_user, n_nb, nb_rank, s_off, s_cnt, s_buf, r_off, r_cnt, r_buf):
+            try:
+                ops, n_s, n_r = [], 0, 0
+                for j in range(n_nb):
+                    n_s = max(n_s, s_off[j] + s_cnt[j])
+                    n_r = max(n_r, r_off[j] + r_cnt[j])
+                sv, rv = view(s_buf, max(n_s, 1)), view(r_buf, max(n_r, 1))
+                for j in range(n_nb):
+                    if s_cnt[j]:
+                        ops.append(tdist.P2POp(tdist.isend, sv[s_off[j]:s_off[j] + s_cnt[j]], int(nb_rank[j]), group=grp))
+                    if r_cnt[j]:
+                        ops.append(tdist.P2POp(tdist.irecv, rv[r_off[j]:r_off[j] + r_cnt[j]], int(nb_rank[j]), group=grp))
+                for req in (tdist.batch_isend_irecv(ops) if ops else []):
+                    req.wait()
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = (backend.ALLREDUCE_FN(allreduce), backend.EXCHANGE_FN(exchange))   # keep the thunks alive
+        t = backend.CHostTransport()
+        t.rank, t.size, t.allreduce, t.exchange, t.user = rank, nparts, self._cb[0], self._cb[1], None
+        self._host_transport = t
 
     # ---- state in GLOBAL (file) vertex order -------------------------------------------------------------------------
     def set_state(self, u_global=None, un_global=None):

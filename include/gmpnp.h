@@ -298,6 +298,22 @@ void gmpnp_comm_destroy(gmpnp_comm* c);
  * become device copies between the handles; this is what the single-GPU test box runs). */
 typedef struct gmpnp_group gmpnp_group;
 int gmpnp_group_create(int32_t n_local, gmpnp_solver* const* handles, gmpnp_comm* comm, gmpnp_group** out);
+/* Third transport: the caller moves the bytes.  The library stages each all-reduce / ghost exchange through pinned host
+ * buffers and calls back; the Python driver implements the two calls with torch.distributed on `gloo`.  For machines
+ * without RCCL between the ranks and for the two-ranks-on-one-card test (RCCL refuses two ranks on one device); every
+ * collective costs two PCIe copies and a stream synchronisation, so this is not a production path.
+ *   allreduce(user, buf, n):  sum buf[0..n) over all ranks, in place, same result on every rank; 0 = ok
+ *   exchange(user, n_neighbours, neighbour_rank, send_offset, send_count, send_buf, recv_offset, recv_count, recv_buf):
+ *       send send_buf[send_offset[j] .. +send_count[j]) (doubles) to neighbour j, receive its message into
+ *       recv_buf[recv_offset[j] .. +recv_count[j]); 0 = ok */
+typedef struct {
+  int32_t rank, size;
+  int (*allreduce)(void* user, double* buf, int32_t n);
+  int (*exchange)(void* user, int32_t n_neighbours, const int32_t* neighbour_rank, const int64_t* send_offset, const int64_t* send_count,
+                  const double* send_buf, const int64_t* recv_offset, const int64_t* recv_count, double* recv_buf);
+  void* user;
+} gmpnp_host_transport_t;
+int gmpnp_group_create_hosted(gmpnp_solver* handle, const gmpnp_host_transport_t* transport, gmpnp_group** out);
 void gmpnp_group_destroy(gmpnp_group* g);
 /* solve(F == 0, u, bcs, solver_parameters) on the partitioned state (each handle's u / u_n hold owned + ghost values, set
  * with gmpnp_set_state; ghost values of u are kept current inside).  Collective: every rank calls it.  Statistics are
