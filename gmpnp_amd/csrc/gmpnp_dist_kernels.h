@@ -12,19 +12,25 @@ struct VecListW { double* p[4]; };
 
 // buf[((k * nvec) + v) * width + f] = src_v[nodes[k] * width + f]: node-major, so the rows for one neighbour (a contiguous
 // range of k) are one contiguous message whatever the number of vectors.
-__global__ __launch_bounds__(256) void k_halo_pack(const VecList src, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
-                                                    double* __restrict__ buf) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void halo_pack_entry(const VecList& src, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                double* __restrict__ buf, int i) {
   if (i >= n_nodes * nvec * width) return;
   const int f = i % width, v = (i / width) % nvec, k = i / (width * nvec);
   buf[i] = src.p[v][(size_t)nodes[k] * width + f];
 }
-__global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
-                                                      const double* __restrict__ buf) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void halo_unpack_entry(const VecListW& dst, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                  const double* __restrict__ buf, int i) {
   if (i >= n_nodes * nvec * width) return;
   const int f = i % width, v = (i / width) % nvec, k = i / (width * nvec);
   dst.p[v][(size_t)nodes[k] * width + f] = buf[i];
+}
+__global__ __launch_bounds__(256) void k_halo_pack(const VecList src, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                    double* __restrict__ buf) {
+  halo_pack_entry(src, nvec, width, nodes, n_nodes, buf, blockIdx.x * 256 + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nvec, int width, const int32_t* __restrict__ nodes, int n_nodes,
+                                                      const double* __restrict__ buf) {
+  halo_unpack_entry(dst, nvec, width, nodes, n_nodes, buf, blockIdx.x * 256 + threadIdx.x);
 }
 
 // One WORKGROUP per output value: a fixed-order sum of per-tile scalar partials or of per-slot restriction partials (a
@@ -33,9 +39,9 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nve
 //   phase 1 (after half A)      out[0..1]             = sum_tile part_a, part_rr ; out[2 + w n + d] = sum_slot (v, r, p)[par]
 //   phase 2 (after half B)      out[0..3]             = sum_tile part_b[m]       ; out[4 + d]       = sum_slot cpart_t
 //   phase 3 (end of a solve)    out[d]                = sum_slot cpart_v[0][slot][d]                 (P^T y, left by k_restrict)
-__global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int par, double* __restrict__ out) {
+__device__ __forceinline__ void dist_reduce_block(const Ctx& c, int phase, int par, double* __restrict__ out, int o) {
   __shared__ double lds[4];
-  const int n = c.ncoarse, o = blockIdx.x, t = threadIdx.x;
+  const int n = c.ncoarse, t = threadIdx.x;
   const int nscal = phase == 1 ? 2 : (phase == 2 ? 4 : 0);
   const double* p; int count, stride;
   if (o < nscal) {
@@ -57,6 +63,30 @@ __global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int
   }
   block_sum<1>(v, lds);
   if (t == 0) out[o] = v[0];
+}
+__global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int par, double* __restrict__ out) {
+  dist_reduce_block(c, phase, par, out, blockIdx.x);
+}
+// The per-rank sums of a half-iteration AND the packing of the ghost rows that follow it, in one launch (partitioned solve):
+// workgroups [0, nout) reduce, the others pack.
+__global__ __launch_bounds__(256) void k_dist_reduce_pack(const Ctx c, int phase, int par, double* __restrict__ out, int nout, const VecList src, int nvec,
+                                                           const int32_t* __restrict__ nodes, int n_nodes, double* __restrict__ buf, int width) {
+  if ((int)blockIdx.x < nout) dist_reduce_block(c, phase, par, out, blockIdx.x);
+  else halo_pack_entry(src, nvec, width, nodes, n_nodes, buf, ((int)blockIdx.x - nout) * 256 + (int)threadIdx.x);
+}
+// Coarse kernel of a half-iteration with the unpacking of the ghost rows received before it riding along: workgroups
+// [0, nagg) are the coarse workgroups, the others scatter the receive buffer (the tile kernel is the next launch).
+template <int NF>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_a_unpack(const Ctx c, const int k, const VecListW dst, int nvec, const int32_t* __restrict__ nodes,
+                                                                    int n_nodes, const double* __restrict__ buf) {
+  if ((int)blockIdx.x < c.nagg) coarse_a_body<NF, false>(c, k, blockIdx.x, 0u);
+  else halo_unpack_entry(dst, nvec, NF, nodes, n_nodes, buf, ((int)blockIdx.x - c.nagg) * kCoarseThreads + (int)threadIdx.x);
+}
+template <int NF>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_b_unpack(const Ctx c, const int k, const VecListW dst, int nvec, const int32_t* __restrict__ nodes,
+                                                                    int n_nodes, const double* __restrict__ buf) {
+  if ((int)blockIdx.x < c.nagg) coarse_b_body<NF, false>(c, k, blockIdx.x, 0u);
+  else halo_unpack_entry(dst, nvec, NF, nodes, n_nodes, buf, ((int)blockIdx.x - c.nagg) * kCoarseThreads + (int)threadIdx.x);
 }
 
 // ||b||^2 of the owned rows (k_res_gather's per-workgroup partials) and the four status bits, as doubles for the all-reduce

@@ -35,16 +35,26 @@ RcclApi* rccl_api(std::string* why) {
   static std::string err;
   if (!tried) {
     tried = true;
-    // One RCCL per HIP runtime.  A process that imported PyTorch first already holds PyTorch's own librccl.so (and this
-    // library then runs on PyTorch's HIP runtime, matched by soname): reuse it.  Otherwise load the system library under
-    // its SONAME only, so that a later `import torch` (which asks for "librccl.so" / "libamdhip64.so" by those names and
-    // finds its bundled copies) keeps its own consistent pair instead of binding to ours.
-    for (const char* name : {"librccl.so", "librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-      if (api.lib) break;
-    }
+    // One RCCL per HIP runtime — and it has to be the one that sits on the HIP runtime THIS library is bound to.  A process
+    // that imports PyTorch holds PyTorch's own libamdhip64.so and librccl.so next to the system's (same sonames): whichever
+    // HIP runtime was loaded first serves this library, and an RCCL bound to the other one fails in ncclCommInitRank
+    // ("unhandled cuda error").  So: find the file our HIP symbols come from and take the librccl.so in ITS directory
+    // (torch/lib for PyTorch's pair, /opt/rocm/lib for the system's); by path, because a name or soname would match
+    // whichever copy happens to be loaded already.
+    std::string dir;
+    { Dl_info info{};
+      if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        const size_t slash = dir.find_last_of('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash);
+      } }
+    if (!dir.empty())
+      for (const char* name : {"/librccl.so", "/librccl.so.1"}) {
+        api.lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+      }
     if (!api.lib)
-      for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (api.lib) break;
       }
@@ -121,18 +131,9 @@ int group_allreduce(gmpnp_group* g, F buf_of, int n) {
 }
 
 // Ghost rows of up to four nodal arrays (`width` doubles per node) from their owners: pack, one message per neighbour, unpack.
-template <class F>
-int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
-  for (gmpnp_solver* s : g->dom) {
-    const int nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
-    if (nsn == 0) continue;
-    VecListW w = vecs_of(s); VecList src{};
-    for (int v = 0; v < 4; ++v) src.p[v] = w.p[v];
-    hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(nsn * nvec * width, 256)), dim3(256), 0, s->stream, src, nvec, width,
-                       (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p);
-  }
-  HIP_TRY(hipGetLastError());
-  const size_t per = (size_t)nvec * width;
+// The messages themselves: what every rank packed into its send buffer (`per` doubles per node) travels to the neighbours'
+// receive buffers — RCCL, host-staged callbacks, or device copies between the handles of one process.
+int group_transfer(gmpnp_group* g, size_t per) {
   if (g->hosted) {
     gmpnp_solver* s = g->dom[0];
     const size_t nb = s->nb_rank.size();
@@ -176,6 +177,21 @@ int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
       }
     }
   }
+  return GMPNP_OK;
+}
+
+template <class F>
+int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
+  for (gmpnp_solver* s : g->dom) {
+    const int nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+    if (nsn == 0) continue;
+    VecListW w = vecs_of(s); VecList src{};
+    for (int v = 0; v < 4; ++v) src.p[v] = w.p[v];
+    hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(nsn * nvec * width, 256)), dim3(256), 0, s->stream, src, nvec, width,
+                       (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p);
+  }
+  HIP_TRY(hipGetLastError());
+  { int rt = group_transfer(g, (size_t)nvec * width); if (rt) return rt; }
   for (gmpnp_solver* s : g->dom) {
     const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back();
     if (nrn == 0) continue;
@@ -257,24 +273,35 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
   const dim3 cg(std::max(1, g->dom[0]->t.nagg));
   KrylovScalars res = init;
   int k = 0;
+  // Per half-iteration and rank THREE launches: [coarse kernel + unpacking of the ghost rows received last], tile kernel,
+  // [per-rank sums + packing of the ghost rows to send]; then the all-reduce and the grouped send/recv.
   auto iteration = [&]() -> int {
     const int par = k & 1;
     for (gmpnp_solver* s : g->dom) {
-      hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back(), nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+      VecListW ub{}; ub.p[0] = s->ks.p; ub.p[1] = s->kt.p;    // what B(k-1) sent (nothing pending before the first iteration)
+      const int un = k > 0 ? nrn : 0;
+      hipLaunchKernelGGL((k_coarse_a_unpack<NF>), dim3(cg.x + grid_for(un * 2 * NF, kCoarseThreads)), dim3(kCoarseThreads), 0, s->stream, s->c, k, ub, 2,
+                         (const int32_t*)s->recv_nodes.p, un, (const double*)s->recvbuf.p);
       hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL(k_dist_reduce, dim3(2 + 3 * n), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p);
+      VecList pa{}; pa.p[0] = s->kr.p; pa.p[1] = s->c.kv[par]; pa.p[2] = s->c.kp[par];
+      hipLaunchKernelGGL(k_dist_reduce_pack, dim3(2 + 3 * n + grid_for(nsn * 3 * NF, 256)), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p, 2 + 3 * n, pa, 3,
+                         (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p, NF);
     }
     int r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_a.p; }, 2 + 3 * n); if (r) return r;
-    r = group_exchange(g, NF, 3, [par](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kr.p; w.p[1] = s->c.kv[par]; w.p[2] = s->c.kp[par]; return w; });
-    if (r) return r;
+    r = group_transfer(g, (size_t)3 * NF); if (r) return r;
     for (gmpnp_solver* s : g->dom) {
-      hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back(), nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+      VecListW ua{}; ua.p[0] = s->kr.p; ua.p[1] = s->c.kv[par]; ua.p[2] = s->c.kp[par];
+      hipLaunchKernelGGL((k_coarse_b_unpack<NF>), dim3(cg.x + grid_for(nrn * 3 * NF, kCoarseThreads)), dim3(kCoarseThreads), 0, s->stream, s->c, k, ua, 3,
+                         (const int32_t*)s->recv_nodes.p, nrn, (const double*)s->recvbuf.p);
       hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL(k_dist_reduce, dim3(4 + n), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p);
+      VecList pb{}; pb.p[0] = s->ks.p; pb.p[1] = s->kt.p;
+      hipLaunchKernelGGL(k_dist_reduce_pack, dim3(4 + n + grid_for(nsn * 2 * NF, 256)), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p, 4 + n, pb, 2,
+                         (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p, NF);
     }
     r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_b.p; }, 4 + n); if (r) return r;
-    r = group_exchange(g, NF, 2, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->ks.p; w.p[1] = s->kt.p; return w; });
-    if (r) return r;
+    r = group_transfer(g, (size_t)2 * NF); if (r) return r;
     ++k;
     HIP_TRY(hipGetLastError());
     return GMPNP_OK;

@@ -1,25 +1,23 @@
-"""Mesh-partitioned Newton solve across ranks: one process per GPU, `torch.distributed` for the ghost
-exchange and the scalar all-reduces (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""Mesh partitioning for the multi-GPU solve (BASELINE configs[3]): one process per GPU.
 
-The reference is a serial script (no MPI call site), so there is no behaviour to match except the serial result
-itself: the partitioned solve must give the serial Newton iterates.
+The reference is a serial script (no MPI call site), so there is no behaviour to match except the serial result itself: the
+partitioned solve must give the serial Newton iterates.
 
-Decomposition.  Vertices are ordered by `backend.slab_permutation` (slabs along the pore axis) and cut into P
-contiguous ranges: rank p OWNS its range.  Its local mesh is every cell that touches an owned vertex; the other
-vertices of those cells are GHOSTS (owned by a neighbouring slab).  Cut cells are assembled redundantly on both sides,
-so the rows of owned vertices are complete without any matrix communication; ghost rows are replaced by identity rows
-(they are never used).  Communication per Newton iteration: one ghost exchange of u; per Krylov iteration: two ghost
-exchanges (one per operator application) and the BiCGStab scalars as fused all-reduces of 5 / 2 doubles.
+Decomposition.  Vertices are ordered by `backend.slab_permutation` (slabs along the pore axis) and cut into P contiguous
+ranges: rank p OWNS its range.  Its local mesh is every cell that touches an owned vertex; the other vertices of those cells
+are GHOSTS (owned by a neighbouring slab).  Cut cells are assembled redundantly on both sides, so the rows of owned vertices
+are complete without any matrix communication; ghost rows are replaced by identity rows (they are never used).
 
-The Krylov loop is driven from this module (right-preconditioned BiCGStab, same recurrences as the device solver),
-calling the rank's backend for the three local operations: assemble, y = A_local x, z = M_local^{-1} r (subdomain
-node-block Jacobi + slab coarse correction: an additive Schwarz preconditioner with minimal overlap).  The vectors are
-either NumPy arrays (``DeviceLocalOps``: every call crosses the C-ABI with host buffers; also what the CPU tests'
-doubles use) or torch tensors resident on the GPU (``TorchDeviceLocalOps``: the ``*_device`` entry points of the
-library take the tensors' device addresses, the ghost exchange and the all-reduces run on the tensors through
-``torch.distributed`` — RCCL on a multi-GPU node, nothing is staged through the host).  On a 3.7k-vertex mesh neither
-can beat one GPU — an RCCL small-message all-reduce costs more than the local SpMV — the mapping that scales there is
-one problem per GPU (bench.py, gmpnp_amd.sweep).
+What this module is:
+* ``partition_plan`` / ``build_local_domain`` — the partition, the halo plan and the global coarse slabs handed to
+  ``gmpnp_create_partition``;
+* ``PartitionedSolver`` — the product path: Newton, BiCGStab, ghost exchanges and all-reduces run INSIDE libgmpnp.so
+  (``gmpnp_group_newton_solve``; RCCL, in-process, or host-staged transport); Python scatters / gathers states and the
+  per-step boundary values;
+* ``Comm``, ``bicgstab``, ``newton_solve``, ``DeviceLocalOps``, ``TorchDeviceLocalOps`` — round 1's host-driven form of the same
+  algorithm (one Python statement per vector operation, subdomain preconditioners without the global coarse level).  Kept as
+  the CPU rehearsal: with a NumPy test double for the three local operations it runs at world size 2 on ``gloo`` without any
+  GPU (tests/test_dist_cpu.py), which the library path cannot.  Not used by the drivers or the bench.
 """
 from __future__ import annotations
 
