@@ -32,7 +32,15 @@ constexpr int kSlicePad = 16;       // per-(slice,kpos) column-index record leng
 #ifndef GMPNP_ROW_PRELOAD_B
 #define GMPNP_ROW_PRELOAD_B 2  // B half of the two-launch form: its register budget allows a second block position up front
 #endif
-constexpr int kRowPad = GMPNP_KRYLOV_WAVES * (GMPNP_ROW_PRELOAD_B > GMPNP_ROW_PRELOAD ? GMPNP_ROW_PRELOAD_B : GMPNP_ROW_PRELOAD);  // block positions of zero padding behind the last slice
+#ifndef GMPNP_CLAMP_PRELOAD
+#define GMPNP_CLAMP_PRELOAD 1  // preload positions past a slice's end repeat its last position instead of reading the next slice
+#endif
+#ifndef GMPNP_ROW_PRELOAD_A
+#define GMPNP_ROW_PRELOAD_A 1  // A half of the two-launch form (2 fits without spilling since the staged s, t wait in LDS, but measured slower: A 13.7 -> 14.1 us and B 11.7 -> 12.7 us)
+#endif
+constexpr int kRowPreMax = GMPNP_ROW_PRELOAD_B > GMPNP_ROW_PRELOAD_A ? (GMPNP_ROW_PRELOAD_B > GMPNP_ROW_PRELOAD ? GMPNP_ROW_PRELOAD_B : GMPNP_ROW_PRELOAD)
+                                                                     : (GMPNP_ROW_PRELOAD_A > GMPNP_ROW_PRELOAD ? GMPNP_ROW_PRELOAD_A : GMPNP_ROW_PRELOAD);
+constexpr int kRowPad = GMPNP_KRYLOV_WAVES * kRowPreMax;  // block positions of zero padding behind the last slice
 
 // Device scalars of one BiCGStab solve.  Each field has ONE writer kernel and is read only by later launches
 // (fields written by kernel A are read by B and vice versa; rho is double-buffered by iteration parity).

@@ -877,15 +877,21 @@ struct PartialSums {
     for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
     if (lane == 0)
 #pragma unroll
-      for (int q = 0; q < K; ++q) lds[w * K + q] = v[q];
+      for (int q = 0; q < K; ++q) lds[q * NWV + w] = v[q];
   }
+  // Totals for every thread: lane 8q + w reads wave w's sum of quantity q (ONE LDS read per lane), three DPP row shifts put the
+  // total of quantity q into lane 8q + 7, a readlane makes it uniform.  (Reading all 8 x K per-wave sums into every thread
+  // costs 16 K registers at the point where the coarse workgroups hold their Aci columns: the fused A launch spilled there.)
+  static constexpr int NWV = kCoarseThreads / 64;
+  static_assert(NWV == 8 && 8 * K <= 64, "one 8-lane group per quantity");
   static __device__ inline void reduce_final(const double* lds, double (&out)[K]) {
+    const int lane = threadIdx.x & 63;
+    double v = lds[min(lane, 8 * K - 1)];
+    v = group8_sum_to_last(v);
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int ww = 0; ww < kCoarseThreads / 64; ++ww) sacc += lds[ww * K + q];
-      out[q] = sacc;
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), 8 * q + 7), hi = __builtin_amdgcn_readlane(__double2hiint(v), 8 * q + 7);
+      out[q] = __hiloint2double(hi, lo);
     }
   }
 };
@@ -991,6 +997,12 @@ struct CoarseRows {
   }
 };
 
+// Load base[byte_off / 8] with a 32-bit byte offset from a wave-uniform base: the scalar-base addressing form, one VGPR per
+// address instead of a 64-bit pair (the tile prologues hold ~50 load destinations at once and have 80 registers).
+__device__ __forceinline__ double ld_off(const double* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // Matrix part shared by the tile kernels: the wave's first PRE blocks are requested up front, x comes from LDS.
 // The preload is unconditional (vals / sell_lcol carry kRowPad block positions of zero padding behind the last
 // slice, positions past a short slice's end just read into the next slice) and masked afterwards.
@@ -1011,10 +1023,19 @@ struct TileRows {
     row = active ? (rec.node0 + Iloc) * NF + i : 0;
     cb = rec.colbase; mx = active ? rec.mx : 0; base = vals + rec.slice_off + lane;
     const int il = min(Iloc, kSlicePad - 1);
+    // Positions past the slice's last block are clamped onto it: the request repeats a line another wave of this tile asks
+    // for anyway instead of pulling a line of the NEXT slice through the fabric (every launch re-reads its bytes from the
+    // memory side — the XCDs' L2s keep nothing across a kernel boundary — and the tile kernels are bound by those bytes:
+    // the unclamped two-position preload of the B half fetched 6.8 MB more than the matrix holds).
+    const int last = GMPNP_CLAMP_PRELOAD ? rec.mx - 1 : (1 << 30);
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
-      const int kp = w + u * kKrylovWaves;
+      const int kp = min(w + u * kKrylovWaves, last);
       lc[u] = c.sell_lcol[(size_t)(cb + kp) * kSlicePad + il];
+    }
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const int kp = min(w + u * kKrylovWaves, last);
 #pragma unroll
       for (int j = 0; j < NF; ++j) av[u][j] = base[(size_t)(kp * NF + j) * kWave];
     }
@@ -1260,6 +1281,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
   __shared__ double dpart[kSlicesPerTile][2];
   __shared__ double xs[kTileCols * NF];
+  __shared__ double xt[MAT ? 1 : kTileCols * NF];  // s and t of the staged entries wait in LDS (xs, xt), not in registers
   __shared__ double ycl[kMaxCoarse];
   __shared__ double own[6][64];
   static_assert(kSlicesPerTile == 1 && NW >= 6, "own-row hand-over: one slice per tile, one wave per vector");
@@ -1290,17 +1312,17 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   TileCoarse<NF> tcs;
   tcs.load_index(c, tile);
   if (!FUSED) tcs.template load_values<false>(c);
-  TileRows<NF> rows;
+  TileRows<NF, (FUSED ? GMPNP_ROW_PRELOAD_A : GMPNP_ROW_PRELOAD)> rows;
   rows.load(c, c.vals_s, rec);
   const int nst = rec.ncols * NF;
   double st_s[kStagePre], st_t[kStagePre], st_p[kStagePre], st_v[kStagePre];
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
-    st_s[u] = sfirst[idx];
+    const unsigned off = ((unsigned)st_col[u] * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
+    st_s[u] = ld_off(sfirst, off);
     if (MAT) { st_t[u] = 0.0; st_p[u] = 0.0; st_v[u] = 0.0; }
-    else { st_t[u] = c.kt[idx]; st_p[u] = po[idx]; st_v[u] = vo[idx]; }  // k = 0: only st_s is used
+    else { st_t[u] = ld_off(c.kt, off); st_p[u] = ld_off(po, off); st_v[u] = ld_off(vo, off); }  // k = 0: only st_s is used
   }
   // own rows (the epilogue of wave 0 needs six vectors at its rows): wave q requests vector q and hands it over through
   // LDS, so that no load sits behind a branch and nobody holds six values
@@ -1308,9 +1330,16 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   const double* ownp = MAT ? (wv == 0 ? c.krhat : wv == 1 ? c.kr : c.kp[par])   // r_k and p_k are in place already
                            : (wv == 0 ? c.krhat : wv == 1 ? sfirst : wv == 2 ? c.kt : wv == 3 ? po : wv == 4 ? vo : c.ky);
   const double own_q = ownp[own_r];
+  // The staged s and t go to LDS as soon as they arrive (they were requested first, so this wait does not cover the matrix
+  // preload): eight registers less behind the hand-over, which is what lets the fused A half preload a second block position
+  // without spilling.  p_old and v_old stay in registers.
+  if (!MAT && !first) {
+#pragma unroll
+    for (int u = 0; u < kStagePre; ++u) { xs[t + u * kKrylovThreads] = st_s[u]; xt[t + u * kKrylovThreads] = st_t[u]; }
+  }
   { double keep = own_q + (FUSED ? 0.0 : tcs.a0 + tcs.a1);
 #pragma unroll
-    for (int u = 0; u < kStagePre; ++u) keep += (st_s[u] + st_t[u]) + (st_p[u] + st_v[u]);
+    for (int u = 0; u < kStagePre; ++u) keep += ((MAT || first) ? st_s[u] + st_t[u] : 0.0) + (st_p[u] + st_v[u]);
 #pragma unroll
     for (int u = 0; u < decltype(rows)::PRE; ++u)
 #pragma unroll
@@ -1330,7 +1359,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     if (q < nst) {
-      const double pj = (first || MAT) ? st_s[u] : (st_s[u] - omega * st_t[u]) + beta * (st_p[u] - omega * st_v[u]);
+      const double pj = (first || MAT) ? st_s[u] : (xs[q] - omega * xt[q]) + beta * (st_p[u] - omega * st_v[u]);
       xs[q] = pj + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
     }
   }
@@ -1426,8 +1455,8 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    const size_t idx = (size_t)st_col[u] * NF + (q - (q / NF) * NF);
-    st_r[u] = MAT ? c.ks[idx] : c.kr[idx]; st_v[u] = MAT ? 0.0 : vn[idx];   // MAT: s_k was written by k_vec_b
+    const unsigned off = ((unsigned)st_col[u] * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
+    st_r[u] = ld_off(MAT ? c.ks : c.kr, off); st_v[u] = MAT ? 0.0 : ld_off(vn, off);   // MAT: s_k was written by k_vec_b
   }
   const int own_r = rows.row;  // inactive lanes: row 0
   const double* ownp = wv == 0 ? c.krhat : wv == 1 ? (MAT ? c.ks : c.kr) : vn;  // wave q requests own-row vector q (see k_bicg_a)
@@ -1499,6 +1528,20 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
   }
 }
 
+// ---- block index -> tile -----------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks q and q + 8 share one; observed, relied on for speed only), and an
+// XCD's L2 serves every tile that runs there during the launch.  Tiles in mesh order are neighbours along the pore axis and
+// stage largely the same column nodes, so XCD x gets a CONTIGUOUS eighth of the tiles: each staged vector line then
+// crosses the fabric once per launch instead of once per XCD.  Sums are indexed by tile, not by block: results do not change.
+#ifndef GMPNP_XCD_TILES
+#define GMPNP_XCD_TILES 1
+#endif
+__device__ __forceinline__ int xcd_tile(int q, int ntiles) {
+  if (!GMPNP_XCD_TILES) return q;
+  const int x = q & (kXcds - 1), i = q >> 3, per = ntiles >> 3, rem = ntiles & (kXcds - 1);
+  return x * per + min(x, rem) + i;
+}
+
 // ---- launch forms ---------------------------------------------------------------------------------------------
 // Four launches per iteration (coarse_a, bicg_a, coarse_b, bicg_b) ...
 template <int NF>
@@ -1506,15 +1549,15 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse_a(const Ctx c, const 
 template <int NF>
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse_b(const Ctx c, const int k) { coarse_b_body<NF, false>(c, k, blockIdx.x, 0u); }
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a(const Ctx c, const int k) { bicg_a_body<NF, false>(c, k, c.tile0 + xcd_tile(blockIdx.x, gridDim.x), 0u); }
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, c.tile0 + blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b(const Ctx c, const int k) { bicg_b_body<NF, false>(c, k, c.tile0 + xcd_tile(blockIdx.x, gridDim.x), 0u); }
 
 // Materialised form (large meshes): the vector recurrences run as their own streaming launches in front of the tile kernels.
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a_mat(const Ctx c, const int k) { bicg_a_body<NF, false, true>(c, k, c.tile0 + blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_a_mat(const Ctx c, const int k) { bicg_a_body<NF, false, true>(c, k, c.tile0 + xcd_tile(blockIdx.x, gridDim.x), 0u); }
 template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b_mat(const Ctx c, const int k) { bicg_b_body<NF, false, true>(c, k, c.tile0 + blockIdx.x, 0u); }
+__global__ __launch_bounds__(kKrylovThreads) void k_bicg_b_mat(const Ctx c, const int k) { bicg_b_body<NF, false, true>(c, k, c.tile0 + xcd_tile(blockIdx.x, gridDim.x), 0u); }
 // y += alpha p_{k-1} + omega s ; r_k = s - omega t ; p_k = r_k + beta (p_{k-1} - omega v_{k-1})   (k = 0: p_0 = r_0), all rows
 __global__ __launch_bounds__(256) void k_vec_a(const Ctx c, const int k) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1546,12 +1589,12 @@ static_assert(kCoarseThreads == kKrylovThreads, "coarse and tile workgroups shar
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_a(const Ctx c, const int k, const unsigned target) {
   if ((int)blockIdx.x < c.nagg) coarse_a_body<NF, true>(c, k, blockIdx.x, target);
-  else bicg_a_body<NF, true>(c, k, c.tile0 + blockIdx.x - c.nagg, target);
+  else bicg_a_body<NF, true>(c, k, c.tile0 + xcd_tile(blockIdx.x - c.nagg, gridDim.x - c.nagg), target);
 }
 template <int NF>
 __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b(const Ctx c, const int k, const unsigned target) {
   if ((int)blockIdx.x < c.nagg) coarse_b_body<NF, true>(c, k, blockIdx.x, target);
-  else bicg_b_body<NF, true>(c, k, c.tile0 + blockIdx.x - c.nagg, target);
+  else bicg_b_body<NF, true>(c, k, c.tile0 + xcd_tile(blockIdx.x - c.nagg, gridDim.x - c.nagg), target);
 }
 
 // Plain y = A x with the UNSCALED matrix (parity hook, partitioned driver); same tiling as the Krylov kernels.
