@@ -12,8 +12,9 @@ t = 0), then EXACTLY K steps from t = 0 are timed between barrier + synchronize 
 all ranks / max-over-ranks time.
 
 N > 1: `value` is the north-star quantity — ONE L_50_R_5 problem, mesh-partitioned over the N GPUs (z-slab partitions,
-one process per GPU; ghost-row exchange and one fused all-reduce per BiCGStab half-iteration over RCCL inside
-libgmpnp.so, global coarse space): strong scaling, Newton iterations of the one problem / max-over-ranks time.  On a
+one process per GPU; ghost-row exchange and one fused all-reduce per BiCGStab half-iteration inside libgmpnp.so — peer
+mailboxes over xGMI, else RCCL, else host-staged — global coarse space): strong scaling, Newton iterations of the one
+problem / max-over-ranks time.  On a
 3.7k-vertex mesh that cannot beat one GPU (a half-iteration is 13 us of kernel against two collectives); `--refine 1|2`
 gives the sizes where it can.  The same invocation first times N independent replicas of the problem, one per GPU (the
 parameter-sweep mapping of BASELINE configs[4], no collective, weak scaling) and reports them under `replicas`; should the
@@ -211,15 +212,23 @@ def main():
         wd = threading.Timer(a.partition_timeout, bail)
         wd.daemon = True
         wd.start()
-        # transports in order of preference: RCCL inside the library (one GPU per rank); the library's host-staged transport
-        # over torch.distributed/gloo (ranks sharing a card in a rehearsal, or RCCL unavailable): same algorithm, PCIe per collective
+        # transports in order of preference: peer mailboxes (one kernel launch per collective: stores into the other ranks'
+        # IPC-mapped mailboxes, xGMI between GPUs); RCCL inside the library; the library's host-staged transport over
+        # torch.distributed/gloo (PCIe per collective): same algorithm in all three
         errors = []
-        for transport in (["rccl"] if backend == "nccl" else []) + ["host"]:
+        order = ["peer"] + (["rccl"] if backend == "nccl" else []) + ["host"]
+        if os.environ.get("GMPNP_BENCH_TRANSPORTS"):   # rehearsal / comparison runs: e.g. "host" or "rccl,host"
+            order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "rccl", "host")]
+        for transport in order:
             try:
                 prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport}, **common)
                 try:
                     pdt = timed(prun)
                     pits, pkry = float(sum(prun.newton_its)), float(prun.sys.krylov_iterations)
+                    # the partitioned run must take the Newton iterations the single-GPU run took (every rank sees the same
+                    # counts): a transport that delivers wrong bytes does not get to report a rate
+                    if world > 1 and pits != float(sum(run.newton_its)):
+                        raise RuntimeError("%d Newton iterations instead of the single-GPU run's %d" % (pits, sum(run.newton_its)))
                     tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     part = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
@@ -307,7 +316,7 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
                 out["config"].update(newton_iterations=part["newton_iterations"], krylov_iterations=part["krylov_iterations"],
                                      parallelism="ONE problem, %d z-slab mesh partitions, one per rank: ghost-row exchange + one fused all-reduce per "
                                                  "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
-                                                 % (world, "RCCL on the solver's stream" if part.get("transport") == "rccl" else "host-staged transport over torch.distributed"))
+                                                 % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
                 out["roofline"]["note"] = "kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)"
                 out["replicas"] = replicas
                 out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "earlier_errors") if k in part}

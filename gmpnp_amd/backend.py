@@ -30,10 +30,12 @@ EXPORTS = [
     "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
     "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
     "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create", "gmpnp_group_create_hosted",
+    "gmpnp_group_peer_begin", "gmpnp_group_peer_connect",
     "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
 COMM_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 
 
 class CMesh(ctypes.Structure):
@@ -156,6 +158,8 @@ def load_library(path: str = None):
     lib.gmpnp_comm_destroy.restype = None
     lib.gmpnp_group_create.argtypes = [c_int32, POINTER(c_void_p), c_void_p, POINTER(c_void_p)]
     lib.gmpnp_group_create_hosted.argtypes = [c_void_p, POINTER(CHostTransport), POINTER(c_void_p)]
+    lib.gmpnp_group_peer_begin.argtypes = [c_void_p, POINTER(c_void_p), ctypes.c_char_p]
+    lib.gmpnp_group_peer_connect.argtypes = [c_void_p, ctypes.c_char_p]
     lib.gmpnp_group_destroy.argtypes = [c_void_p]
     lib.gmpnp_group_destroy.restype = None
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]

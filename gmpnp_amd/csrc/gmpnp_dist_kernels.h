@@ -120,6 +120,86 @@ __global__ __launch_bounds__(256) void k_zero_foreign_rows(double* __restrict__ 
   if (r < row0 || r >= row1) Ac[q] = 0.0;
 }
 
+// ---- peer-mailbox transport -------------------------------------------------------------------------------------------------
+// One process per rank.  Every rank owns a MAILBOX in its GPU's memory (uncached allocation, mapped into every other rank's
+// process through an IPC handle; over xGMI when the ranks sit on different GPUs).  An exchange is ONE launch of one
+// workgroup per rank: it stores its contribution to an all-reduce into every rank's mailbox and its ghost-row messages into
+// the neighbours' (system-scope stores), fences, raises its flag in every mailbox to the exchange's sequence number, waits
+// until every rank's flag in its OWN mailbox has reached that number, sums the contributions in rank order (the same order,
+// hence the same bits, on every rank) and copies the received rows into the handle's receive buffer.  No collective library,
+// no host step; a half-iteration of the partitioned BiCGStab costs one such launch instead of an all-reduce and a grouped
+// send/receive.  Slots alternate with the parity of the sequence number: a rank can be at most one exchange ahead of the
+// slowest (it needs everybody's flag of exchange k to finish k, and a rank raises k only after it has consumed k - 1).
+// Mailbox layout (bytes): [flags: kPeerMax x 128] [recv-offset table: kPeerMax x int32 at 1024] [red at red_off: 2 x size x
+// red_cap doubles] [halo at halo_off: per neighbour segment j both parities side by side, (2 recv_ptr[j] + parity len_j) wmax].
+constexpr int kPeerMax = 8;       // ranks of a partition
+constexpr int kPeerNbMax = 8;     // neighbours of one rank
+constexpr int kPeerFlagStride = 32;  // uint32 words between two flags (one 128-B line each)
+constexpr size_t kPeerTableOff = 1024, kPeerRedOff = 2048;
+struct PeerArgs {
+  unsigned char* box[kPeerMax];   // every rank's mailbox as mapped in THIS process (box[me]: the own allocation)
+  int me, size;
+  unsigned seq;                   // number of this exchange: the same on every rank, strictly increasing
+  size_t halo_off;                // byte offset of the ghost-row area (the same on every rank: red_cap is)
+  int red_cap, wmax;              // doubles per contribution slot; widest ghost row (doubles per node) = unit of the halo area
+  int n_nb, nb_rank[kPeerNbMax], send_ptr[kPeerNbMax + 1], recv_ptr[kPeerNbMax + 1];   // node offsets, as in the handle
+  int peer_recv_ptr[kPeerNbMax];  // recv_ptr of THIS rank's segment in neighbour j's plan
+  int32_t* err;                   // pinned host word (bit 0: a flag did not arrive within the budget)
+};
+__device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// red_src[0..n_red) summed over the ranks into red_dst (n_red = 0: no all-reduce); `per` doubles per ghost node from sendbuf to the
+// neighbours and from them into recvbuf (per = 0: no rows)
+__global__ __launch_bounds__(1024) void k_peer_exchange(const PeerArgs a, const double* __restrict__ red_src, int n_red, double* __restrict__ red_dst,
+                                                        const double* __restrict__ sendbuf, double* __restrict__ recvbuf, int per) {
+  const int t = threadIdx.x, nt = blockDim.x, par = a.seq & 1;
+  if (n_red > 0)
+    for (int q = 0; q < a.size; ++q) {
+      double* dst = reinterpret_cast<double*>(a.box[q] + kPeerRedOff) + ((size_t)par * a.size + a.me) * a.red_cap;
+      for (int i = t; i < n_red; i += nt) st_sys(dst + i, red_src[i]);
+    }
+  if (per > 0)
+    for (int j = 0; j < a.n_nb; ++j) {
+      const int len = a.send_ptr[j + 1] - a.send_ptr[j], n = len * per;
+      const double* src = sendbuf + (size_t)a.send_ptr[j] * per;
+      double* dst = reinterpret_cast<double*>(a.box[a.nb_rank[j]] + a.halo_off) + ((size_t)2 * a.peer_recv_ptr[j] + (size_t)par * len) * a.wmax;
+      for (int i = t; i < n; i += nt) st_sys(dst + i, src[i]);
+    }
+  __threadfence_system();   // every thread: its stores are out before the workgroup's flags
+  __syncthreads();
+  if (t < a.size)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(a.box[t]) + a.me * kPeerFlagStride, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t < a.size) {
+    const unsigned* f = reinterpret_cast<const unsigned*>(a.box[a.me]) + t * kPeerFlagStride;
+    const unsigned long long t0 = wall_clock64();
+    // signed distance: sequence numbers may wrap
+    while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
+      if (wall_clock64() - t0 > 500000000ull) {   // 5 s at 100 MHz: a rank is gone; end the launch, the host raises
+        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  if (n_red > 0) {
+    const double* mine = reinterpret_cast<const double*>(a.box[a.me] + kPeerRedOff) + (size_t)par * a.size * a.red_cap;
+    for (int i = t; i < n_red; i += nt) {
+      double acc = 0.0;
+      for (int q = 0; q < a.size; ++q) acc += ld_sys(mine + (size_t)q * a.red_cap + i);
+      red_dst[i] = acc;
+    }
+  }
+  if (per > 0)
+    for (int j = 0; j < a.n_nb; ++j) {
+      const int len = a.recv_ptr[j + 1] - a.recv_ptr[j], n = len * per;
+      const double* src = reinterpret_cast<const double*>(a.box[a.me] + a.halo_off) + ((size_t)2 * a.recv_ptr[j] + (size_t)par * len) * a.wmax;
+      double* dst = recvbuf + (size_t)a.recv_ptr[j] * per;
+      for (int i = t; i < n; i += nt) dst[i] = ld_sys(src + i);
+    }
+}
+
 // In-process rehearsal transport: sum over the handles of one process, written back to all of them (fixed order)
 struct PtrList { double* p[8]; };
 __global__ __launch_bounds__(256) void k_local_allreduce(const PtrList bufs, int nb, int n) {

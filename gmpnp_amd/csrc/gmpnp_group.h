@@ -7,9 +7,10 @@
 // Nothing of the loop runs on the host except the launches; the host reads the device's verdict once per burst, and every
 // rank launches the same bursts (the burst schedule depends only on all-reduced quantities), so the collectives pair up.
 //
-// Transports: RCCL (one process per GPU; ncclAllReduce / grouped ncclSend+ncclRecv on the solver's stream, librccl.so loaded
-// with dlopen on first use) or, for a group that holds ALL ranks of the partition in one process, device copies between the
-// handles on one shared stream (rehearsal of the whole algorithm on a single GPU).
+// Transports: peer mailboxes (one process per rank; every collective is ONE k_peer_exchange launch that stores into the other
+// ranks' IPC-mapped mailboxes — over xGMI between GPUs — and waits on its own flags: gmpnp_dist_kernels.h); RCCL (ncclAllReduce /
+// grouped ncclSend+ncclRecv on the solver's stream, librccl.so loaded with dlopen on first use); host-staged callbacks; or, for
+// a group that holds ALL ranks of the partition in one process, device copies between the handles on one shared stream.
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -96,6 +97,12 @@ struct gmpnp_group {
   std::vector<hipStream_t> own_stream;  // in-process mode: the handles' own streams, given back at destroy
   std::vector<std::vector<int>> peer_slot;  // in-process mode: peer_slot[d][j] = index of d in the neighbour list of d's neighbour j
   int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
+  // peer-mailbox transport (gmpnp_group_peer_begin / _connect): one k_peer_exchange launch per collective, no library, no host step
+  bool peer = false, peer_connected = false;
+  unsigned char* box = nullptr; size_t box_bytes = 0;   // own mailbox (uncached device memory)
+  void* peer_map[kPeerMax] = {};                          // the other ranks' mailboxes as mapped here (IPC)
+  PeerArgs pa{};
+  int32_t* h_peer_err = nullptr;                          // pinned
   // caller-provided transport (gmpnp_group_create_hosted): collectives staged through pinned host memory
   bool hosted = false; gmpnp_host_transport_t host{};
   double* h_stage = nullptr; size_t h_stage_n = 0;   // pinned: [send | recv] or the all-reduce buffer
@@ -104,9 +111,24 @@ struct gmpnp_group {
 
 namespace {
 
+// ---- peer-mailbox transport: one launch = all-reduce of `n_red` doubles (in place) and / or the ghost rows (`per` doubles a node) ----
+int peer_exchange(gmpnp_group* g, double* red, int n_red, size_t per) {
+  gmpnp_solver* s = g->dom[0];
+  if (!g->peer_connected) return fail(GMPNP_ERR_INVALID, "peer transport: gmpnp_group_peer_connect has not been called");
+  if (n_red > g->pa.red_cap) return fail(GMPNP_ERR_INVALID, "peer transport: all-reduce larger than the mailbox slot");
+  if ((int)per > g->pa.wmax) return fail(GMPNP_ERR_INVALID, "peer transport: ghost rows wider than the mailbox unit");
+  if (*g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s (rank gone, or its process ended with an error)");
+  g->pa.seq++;
+  hipLaunchKernelGGL(k_peer_exchange, dim3(1), dim3(1024), 0, s->stream, g->pa, (const double*)red, n_red, red,
+                     (const double*)s->sendbuf.p, s->recvbuf.p, (int)per);
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
 // ---- collectives over the local handles ------------------------------------------------------------------------------------
 template <class F>
 int group_allreduce(gmpnp_group* g, F buf_of, int n) {
+  if (g->peer) return peer_exchange(g, buf_of(g->dom[0]), n, 0);
   if (g->hosted) {
     gmpnp_solver* s = g->dom[0];
     if ((size_t)n > g->h_stage_n) return fail(GMPNP_ERR_INVALID, "hosted transport: staging buffer too small");
@@ -134,6 +156,7 @@ int group_allreduce(gmpnp_group* g, F buf_of, int n) {
 // The messages themselves: what every rank packed into its send buffer (`per` doubles per node) travels to the neighbours'
 // receive buffers — RCCL, host-staged callbacks, or device copies between the handles of one process.
 int group_transfer(gmpnp_group* g, size_t per) {
+  if (g->peer) return peer_exchange(g, nullptr, 0, per);
   if (g->hosted) {
     gmpnp_solver* s = g->dom[0];
     const size_t nb = s->nb_rank.size();
@@ -180,6 +203,14 @@ int group_transfer(gmpnp_group* g, size_t per) {
   return GMPNP_OK;
 }
 
+// the all-reduce AND the ghost rows of a BiCGStab half-iteration: one launch on the peer transport, two collectives otherwise
+template <class F>
+int group_reduce_transfer(gmpnp_group* g, F buf_of, int n, size_t per) {
+  if (g->peer) return peer_exchange(g, buf_of(g->dom[0]), n, per);
+  int r = group_allreduce(g, buf_of, n); if (r) return r;
+  return group_transfer(g, per);
+}
+
 template <class F>
 int group_exchange(gmpnp_group* g, int width, int nvec, F vecs_of) {
   for (gmpnp_solver* s : g->dom) {
@@ -215,6 +246,7 @@ int group_residual(gmpnp_group* g, double* norm, int* flags) {
   gmpnp_solver* s0 = g->dom[0];
   HIP_TRY(hipMemcpyAsync(s0->h_red, s0->red_norm.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
   HIP_TRY(hipStreamSynchronize(s0->stream));
+  if (g->peer && *g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
   *norm = std::sqrt(s0->h_red[0]);
   int f = 0;
   for (int b = 0; b < 4; ++b) if (s0->h_red[1 + b] > 0.0) f |= 1 << b;
@@ -253,17 +285,20 @@ int group_setup(gmpnp_group* g, int mode) {
 }
 
 // ---- BiCGStab across the ranks: rhs in kr (owned rows; k_res_gather left it there), ||rhs|| = bnorm (global); leaves y in ky ----
+// random_shadow: the shadow vector of this pass is each handle's krand (filled by the caller) and (rhat, r_0) = shadow_rho0
 template <int NF>
-int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st, bool sized_by_previous = true) {
+int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st, bool sized_by_previous = true,
+                 bool random_shadow = false, double shadow_rho0 = 0.0) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   const int n = g->dom[0]->ncoarse;
   KrylovScalars init{};
-  init.rho[0] = init.rho[1] = bnorm * bnorm; init.alpha = 1.0;
+  init.rho[0] = init.rho[1] = random_shadow ? shadow_rho0 : bnorm * bnorm; init.alpha = 1.0;
   init.tol = std::max(rtol * bnorm, atol); init.rr = bnorm * bnorm; init.max_iters = maxit; init.rr0 = bnorm * bnorm;
   if (!(bnorm > 0.0)) init.done = 1;
   for (gmpnp_solver* s : g->dom) {
     s->c.use_coarse = use_coarse;
-    hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c, (const double*)nullptr, init, s->cpart_v1.p);
+    hipLaunchKernelGGL((k_krylov_init<NF>), dim3(s->t.own_ntiles), dim3(kVecBlock), 0, s->stream, s->c,
+                       random_shadow ? (const double*)s->krand.p : (const double*)nullptr, init, s->cpart_v1.p);
     if (use_coarse) hipLaunchKernelGGL(k_dist_reduce, dim3(n), dim3(256), 0, s->stream, s->c, 0, 0, s->red_i.p);
   }
   HIP_TRY(hipGetLastError());
@@ -288,8 +323,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
       hipLaunchKernelGGL(k_dist_reduce_pack, dim3(2 + 3 * n + grid_for(nsn * 3 * NF, 256)), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p, 2 + 3 * n, pa, 3,
                          (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p, NF);
     }
-    int r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_a.p; }, 2 + 3 * n); if (r) return r;
-    r = group_transfer(g, (size_t)3 * NF); if (r) return r;
+    int r = group_reduce_transfer(g, [](gmpnp_solver* s) { return s->red_a.p; }, 2 + 3 * n, (size_t)3 * NF); if (r) return r;
     for (gmpnp_solver* s : g->dom) {
       const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back(), nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
       VecListW ua{}; ua.p[0] = s->kr.p; ua.p[1] = s->c.kv[par]; ua.p[2] = s->c.kp[par];
@@ -300,8 +334,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
       hipLaunchKernelGGL(k_dist_reduce_pack, dim3(4 + n + grid_for(nsn * 2 * NF, 256)), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p, 4 + n, pb, 2,
                          (const int32_t*)s->send_nodes.p, nsn, s->sendbuf.p, NF);
     }
-    r = group_allreduce(g, [](gmpnp_solver* s) { return s->red_b.p; }, 4 + n); if (r) return r;
-    r = group_transfer(g, (size_t)2 * NF); if (r) return r;
+    r = group_reduce_transfer(g, [](gmpnp_solver* s) { return s->red_b.p; }, 4 + n, (size_t)2 * NF); if (r) return r;
     ++k;
     HIP_TRY(hipGetLastError());
     return GMPNP_OK;
@@ -316,6 +349,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
       for (int it = 0; it < burst; ++it) { rc = iteration(); if (rc) return rc; }
       HIP_TRY(hipMemcpyAsync(&s0->h_scal[0], s0->scal.p, sizeof(KrylovScalars), hipMemcpyDeviceToHost, s0->stream));
       for (gmpnp_solver* s : g->dom) HIP_TRY(hipStreamSynchronize(s->stream));
+      if (g->peer && *g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
       res = s0->h_scal[0];
       if (res.done) break;
       if (k > maxit + 8) break;
@@ -403,9 +437,41 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
         warm = true; rstart = std::sqrt(rn2);
       }
     }
+    int kry_total = 0;
     if (warm && rstart <= tol_abs) { ls.converged = 1; ls.residual_norm = rstart; for (gmpnp_solver* s : g->dom) HIP_TRY(hipMemsetAsync(s->ky.p, 0, s->ndof * sizeof(double), s->stream)); }
-    else rc = group_krylov<NF>(g, o.linear_solver, rstart, warm ? 0.0 : o.krylov_relative_tolerance, warm ? tol_abs : o.krylov_absolute_tolerance,
-                               o.krylov_maximum_iterations, &ls, st.iterations > 0);
+    else {
+      // BiCGStab can break down, or spike past 1e5 times its starting residual, on one (right-hand side, shadow vector) pair
+      // and run smoothly on another: such a pass is thrown away and repeated with a pseudo-random shadow vector — the
+      // second time also without the predicted start — as the single-GPU solver does (gmpnp_api.hip, linear_solve).  The
+      // verdict comes from all-reduced sums, so every rank takes the same branch.
+      bool random_shadow = false; double rho0 = 0.0;
+      for (int attempt = 0;; ++attempt) {
+        rc = group_krylov<NF>(g, o.linear_solver, rstart, warm ? 0.0 : o.krylov_relative_tolerance, warm ? tol_abs : o.krylov_absolute_tolerance,
+                              o.krylov_maximum_iterations, &ls, st.iterations > 0 && attempt == 0, random_shadow, rho0);
+        kry_total += ls.iterations;
+        if (rc != GMPNP_ERR_LINEAR || attempt >= 4 || g->dom[0]->last_done != 3) break;
+        if (warm && attempt >= 1) { warm = false; rstart = r; }
+        for (gmpnp_solver* s : g->dom) {
+          const int nd = s->ndof;
+          HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+          if (warm) {   // kr = b - J x0 again (kt was a work vector of the lost pass)
+            hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, (const double*)s->kx.p, s->kt.p);
+            hipLaunchKernelGGL(k_start_residual, dim3(grid_for(nd, 256)), dim3(256), 0, s->stream, s->kr.p, (const double*)s->kb.p, (const double*)s->kt.p, nd);
+          } else HIP_TRY(hipMemcpyAsync(s->kr.p, s->kb.p, nd * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+          hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(nd, 256)), dim3(256), 0, s->stream, s->krand.p, (unsigned)((attempt + 1) * 2654435761u), nd);
+          hipLaunchKernelGGL(k_dots3, dim3(s->n_resblocks), dim3(kVecBlock), 0, s->stream, (const double*)s->krand.p, (const double*)s->kr.p, s->c.part_f, nd,
+                             s->n_resblocks, s->t.own_node0 * NF, s->t.own_node1 * NF);
+          hipLaunchKernelGGL(k_dots3_reduce, dim3(1), dim3(256), 0, s->stream, (const double*)s->c.part_f, s->n_resblocks, s->red_norm.p);
+        }
+        HIP_TRY(hipGetLastError());
+        { int r2 = group_allreduce(g, [](gmpnp_solver* s) { return s->red_norm.p; }, 3); if (r2) return r2; }
+        gmpnp_solver* s0 = g->dom[0];
+        HIP_TRY(hipMemcpyAsync(s0->h_red, s0->red_norm.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
+        HIP_TRY(hipStreamSynchronize(s0->stream));
+        rho0 = s0->h_red[0]; random_shadow = true;   // (rhat, r_0) of the new shadow vector, over all ranks' owned rows
+      }
+      ls.iterations = kry_total;
+    }
     if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
     st.krylov_iterations += ls.iterations;
     if (rc) return rc;
@@ -556,8 +622,81 @@ int gmpnp_group_create_hosted(gmpnp_solver* handle, const gmpnp_host_transport_t
   return GMPNP_OK;
 }
 
+// Peer-mailbox transport, step 1: allocate this rank's mailbox and hand out its IPC handle.  The caller gathers the handles of
+// all ranks (any channel: the Python driver uses torch.distributed.all_gather) and calls gmpnp_group_peer_connect.
+int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_handle[GMPNP_PEER_HANDLE_BYTES]) {
+  static_assert(GMPNP_PEER_HANDLE_BYTES == sizeof(hipIpcMemHandle_t), "IPC handle size");
+  if (!handle || !out || !ipc_handle) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (!handle->partitioned) return fail(GMPNP_ERR_INVALID, "group members must come from gmpnp_create_partition");
+  if (handle->part_size > kPeerMax) return fail(GMPNP_ERR_INVALID, "peer transport: at most 8 ranks");
+  if (handle->nb_rank.size() > (size_t)kPeerNbMax) return fail(GMPNP_ERR_INVALID, "peer transport: at most 8 neighbours per rank");
+  std::unique_ptr<gmpnp_group> g(new gmpnp_group);
+  g->dom.push_back(handle);
+  g->peer = true;
+  HIP_TRY(hipSetDevice(handle->opts.device_id));
+  PeerArgs& a = g->pa;
+  a.me = handle->part_rank; a.size = handle->part_size; a.seq = 0;
+  const size_t n = (size_t)handle->ncoarse;
+  a.red_cap = (int)std::max<size_t>({n * n, 2 + 3 * n, (size_t)8});
+  a.red_cap = (a.red_cap + 15) & ~15;
+  a.wmax = handle->nf * handle->nf;
+  a.halo_off = kPeerRedOff + (size_t)2 * a.size * a.red_cap * sizeof(double);
+  a.n_nb = (int)handle->nb_rank.size();
+  for (int j = 0; j < a.n_nb; ++j) a.nb_rank[j] = handle->nb_rank[j];
+  for (int j = 0; j <= a.n_nb; ++j) { a.send_ptr[j] = handle->send_ptr[j]; a.recv_ptr[j] = handle->recv_ptr[j]; }
+  g->box_bytes = a.halo_off + (size_t)2 * std::max(1, handle->recv_ptr.back()) * a.wmax * sizeof(double);
+  // uncached: a peer's stores (and this rank's polls of them) must not meet a stale line in this GPU's L2
+  HIP_TRY(hipExtMallocWithFlags((void**)&g->box, g->box_bytes, hipDeviceMallocUncached));
+  HIP_TRY(hipMemset(g->box, 0, g->box_bytes));
+  // where each neighbour's rows start in THIS rank's ghost-row area: the neighbour reads its entry after mapping the mailbox
+  std::vector<int32_t> table(kPeerMax, -1);
+  for (int j = 0; j < a.n_nb; ++j) table[a.nb_rank[j]] = a.recv_ptr[j];
+  HIP_TRY(hipMemcpy(g->box + kPeerTableOff, table.data(), kPeerMax * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipHostMalloc((void**)&g->h_peer_err, sizeof(int32_t)));
+  *g->h_peer_err = 0;
+  a.err = g->h_peer_err;
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, g->box));
+  std::memcpy(ipc_handle, &h, sizeof h);
+  *out = g.release();
+  return GMPNP_OK;
+}
+
+// Step 2: map the other ranks' mailboxes (all_handles: [size][GMPNP_PEER_HANDLE_BYTES], rank order).  Every rank must have
+// returned from gmpnp_group_peer_begin before any rank calls this (the gather of the handles is that point).
+int gmpnp_group_peer_connect(gmpnp_group* g, const char* all_handles) {
+  if (!g || !all_handles || !g->peer) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  if (g->peer_connected) return GMPNP_OK;
+  gmpnp_solver* s = g->dom[0];
+  HIP_TRY(hipSetDevice(s->opts.device_id));
+  PeerArgs& a = g->pa;
+  for (int q = 0; q < a.size; ++q) {
+    if (q == a.me) { a.box[q] = g->box; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, all_handles + (size_t)q * GMPNP_PEER_HANDLE_BYTES, sizeof h);
+    HIP_TRY(hipIpcOpenMemHandle(&g->peer_map[q], h, hipIpcMemLazyEnablePeerAccess));
+    a.box[q] = (unsigned char*)g->peer_map[q];
+  }
+  for (int j = 0; j < a.n_nb; ++j) {
+    int32_t off = -1;
+    HIP_TRY(hipMemcpy(&off, a.box[a.nb_rank[j]] + kPeerTableOff + (size_t)a.me * sizeof(int32_t), sizeof off, hipMemcpyDeviceToHost));
+    if (off < 0) return fail(GMPNP_ERR_INVALID, "peer transport: a neighbour's plan has no segment for this rank");
+    a.peer_recv_ptr[j] = off;
+  }
+  g->peer_connected = true;
+  return GMPNP_OK;
+}
+
 void gmpnp_group_destroy(gmpnp_group* g) {
   if (!g) return;
+  if (g->peer) {   // (the caller has made sure that no rank is still inside an exchange: a barrier of its own)
+    if (!g->dom.empty()) { (void)hipSetDevice(g->dom[0]->opts.device_id); (void)hipStreamSynchronize(g->dom[0]->stream); }
+    for (int q = 0; q < kPeerMax; ++q) if (g->peer_map[q]) (void)hipIpcCloseMemHandle(g->peer_map[q]);
+    if (g->box) (void)hipFree(g->box);
+    if (g->h_peer_err) (void)hipHostFree(g->h_peer_err);
+  }
   if (g->h_stage) (void)hipHostFree(g->h_stage);
   if (!g->dom.empty()) { (void)hipSetDevice(g->dom[0]->opts.device_id); (void)hipStreamSynchronize(g->dom[0]->stream); }
   for (size_t d = 1; d < g->own_stream.size(); ++d) if (g->own_stream[d]) g->dom[d]->stream = g->own_stream[d];

@@ -478,9 +478,10 @@ class PartitionedSolver:
 
     def __init__(self, prob: Problem, nparts: int, rank: int = None, device_id: int = 0, n_global_aggregates: int = None,
                  use_torch_dist: bool = True, transport: str = "rccl", **device_kwargs):
-        """``transport`` (one rank per process only): "rccl" — collectives inside the library over RCCL; "host" — the library
-        stages every collective through pinned host memory and calls back into ``torch.distributed`` (any backend, e.g.
-        gloo): for ranks that share one GPU (RCCL refuses that) and for machines without RCCL between the ranks."""
+        """``transport`` (one rank per process only): "peer" — peer mailboxes: every collective is one kernel launch per rank
+        that stores into the other ranks' IPC-mapped mailboxes (xGMI between GPUs; also works for ranks sharing a card);
+        "rccl" — collectives inside the library over RCCL; "host" — the library stages every collective through pinned host
+        memory and calls back into ``torch.distributed`` (any backend, e.g. gloo)."""
         from ctypes import byref, c_void_p, create_string_buffer
         from . import backend
         self.backend = backend
@@ -495,6 +496,23 @@ class PartitionedSolver:
             self.devs.append(backend.DeviceSolver(dom.problem, device_id=device_id, perm=perm, partition=part, **device_kwargs))
         self._comm = c_void_p()
         self._group = c_void_p()
+        self.transport = transport if rank is not None else "in-process"
+        if rank is not None and transport == "peer":
+            import torch
+            import torch.distributed as tdist
+            if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() == nparts):
+                raise RuntimeError("the peer transport needs an initialised torch.distributed group of %d ranks (to gather the mailbox handles)" % nparts)
+            mine = create_string_buffer(backend.PEER_HANDLE_BYTES)
+            self._check(self.lib.gmpnp_group_peer_begin(self.devs[0]._h, byref(self._group), mine))
+            dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=dev)
+            parts = [torch.empty_like(t) for _ in range(nparts)]
+            tdist.all_gather(parts, t)      # also the point after which every rank's mailbox exists
+            allh = create_string_buffer(backend.PEER_HANDLE_BYTES * nparts)
+            allh.raw = b"".join(bytes(x.cpu().tolist()) for x in parts)
+            self._check(self.lib.gmpnp_group_peer_connect(self._group, allh))
+            tdist.barrier()                 # nobody stores into a mailbox its owner has not finished setting up... and all are mapped
+            return
         if rank is not None and transport == "host":
             self._make_host_transport(rank, nparts)
             self._check(self.lib.gmpnp_group_create_hosted(self.devs[0]._h, byref(self._host_transport), byref(self._group)))
@@ -644,6 +662,13 @@ class PartitionedSolver:
         self._check(self.lib.gmpnp_group_assign_previous(self._group))
 
     def close(self):
+        if getattr(self, "transport", None) == "peer" and getattr(self, "_group", None):
+            try:   # no rank unmaps / frees a mailbox another rank may still store into
+                import torch.distributed as tdist
+                if tdist.is_available() and tdist.is_initialized():
+                    tdist.barrier()
+            except Exception:  # noqa: BLE001
+                pass
         if getattr(self, "_group", None):
             self.lib.gmpnp_group_destroy(self._group)
             self._group = None

@@ -314,6 +314,19 @@ typedef struct {
   void* user;
 } gmpnp_host_transport_t;
 int gmpnp_group_create_hosted(gmpnp_solver* handle, const gmpnp_host_transport_t* transport, gmpnp_group** out);
+/* Fourth transport: peer mailboxes — the one to use with one process per GPU.  Every rank owns a mailbox in its GPU's memory
+ * (uncached), mapped into the other ranks' processes through an IPC handle; a collective is ONE kernel launch per rank that
+ * stores its contribution / its ghost rows straight into the other ranks' mailboxes (xGMI between GPUs), raises a flag there
+ * and waits for the flags in its own: no collective library and no host step between two BiCGStab half-iterations.
+ *   1. every rank: gmpnp_group_peer_begin(handle, &group, my_handle)         -> 64 bytes to publish
+ *   2. the caller gathers the handles of all ranks in rank order (any channel; this gather is also the point after which
+ *      every mailbox exists), then every rank: gmpnp_group_peer_connect(group, all_handles)
+ *   3. gmpnp_group_newton_solve ... ; before gmpnp_group_destroy the caller makes sure (a barrier of its own) that no rank is
+ *      still inside a solve.
+ * A rank that does not arrive within 5 s ends the others' launch with an error instead of a hang. */
+#define GMPNP_PEER_HANDLE_BYTES 64
+int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_handle[GMPNP_PEER_HANDLE_BYTES]);
+int gmpnp_group_peer_connect(gmpnp_group* g, const char* all_handles);
 void gmpnp_group_destroy(gmpnp_group* g);
 /* solve(F == 0, u, bcs, solver_parameters) on the partitioned state (each handle's u / u_n hold owned + ghost values, set
  * with gmpnp_set_state; ghost values of u are kept current inside).  Collective: every rank calls it.  Statistics are

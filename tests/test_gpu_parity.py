@@ -907,7 +907,49 @@ def test_bench_partitioned_code_path_at_world_size_one(gpu_lib):
     assert out["n_gpus"] == 1 and out["scaling"] == "weak"
 
 
-def _library_partition_worker(rank, world, port, out_dir):
+@pytest.mark.parametrize("nparts", [4, 8])
+def test_partitioned_time_loop_survives_krylov_breakdowns(gpu_lib, nparts):
+    """Twelve time steps of the bench problem on 4 / 8 partitions (all ranks in one process): 88 linear solves, some of which
+    break down in their first pass on these partitions (BiCGStab spikes past 1e5 times its starting residual after a warm
+    start) and are repeated with a pseudo-random shadow vector.  Newton counts equal the single-GPU run's at every step."""
+    from gmpnp_amd.pore3d import PoreRun
+    common = dict(num_steps=12, concentration_elec=0.5, L=50e-9, R=5e-9)
+    ref = PoreRun(**common)
+    run = PoreRun(partition=(nparts, None), **common)
+    try:
+        for _ in range(12):
+            ref.step(verbose=False)
+            run.step(verbose=False)
+        assert run.newton_its == ref.newton_its
+        assert relerr(np.asarray(run.history[-1]), np.asarray(ref.history[-1])) < 1e-9
+        assert run.sys.krylov_iterations < 1.3 * ref.sys.krylov_iterations
+    finally:
+        run.sys.close()
+        ref.sys.close()
+
+
+def test_bench_two_ranks_share_the_card_over_peer_mailboxes():
+    """The driver's N = 2 invocation of bench.py (torch.distributed.run, one process per rank), rehearsed with both ranks on the
+    test box's one GPU (GMPNP_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): the replica phase, then ONE problem on
+    two mesh partitions over the peer-mailbox transport, Newton counts equal to the single-GPU run's."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GMPNP_BENCH_BACKEND="gloo")
+    port = 29500 + (os.getpid() % 400) + 63
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong", out
+    assert out["partitioned"]["transport"] == "peer" and "earlier_errors" not in out["partitioned"], out["partitioned"]
+    assert out["config"]["newton_iterations"] * 2 == out["replicas"]["newton_iterations"]
+    assert out["value"] > 0 and out["replicas"]["value"] > 0
+
+
+def _library_partition_worker(rank, world, port, out_dir, transport="host"):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -924,13 +966,16 @@ def _library_partition_worker(rank, world, port, out_dir):
         mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
         prob, _ = pore_problem(pp, mesh)
         nv = mesh.num_vertices
-        with dist.PartitionedSolver(prob, world, rank=rank, transport="host") as ps:
+        with dist.PartitionedSolver(prob, world, rank=rank, transport=transport) as ps:
             ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
+            import time
+            t0 = time.perf_counter()
             st = ps.newton_solve(backend.newton_options(MUMPS_09))
+            wall = time.perf_counter() - t0
             ug = ps.get_state()
         if rank == 0:
             np.savez(os.path.join(out_dir, "libdist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
-                     kits=np.array(st["krylov_per_iteration"]))
+                     kits=np.array(st["krylov_per_iteration"]), wall=wall)
     finally:
         tdist.destroy_process_group()
 
@@ -949,6 +994,25 @@ def test_library_partitioned_solve_two_processes_on_one_card(gpu_lib, tmp_path):
     assert relerr(d["u"], g["states"][0]) < 1e-8
     assert np.allclose(d["res"], g["residuals"][0][: len(d["res"])], rtol=1e-4)
     assert d["kits"].sum() < 700     # the single-GPU solver needs about 450 BiCGStab iterations for this solve
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_mailbox_transport_between_processes_on_one_card(gpu_lib, tmp_path, world):
+    """The peer-mailbox transport between real PROCESSES: every rank maps the others' mailboxes through IPC handles, every
+    collective of the partitioned Newton solve is one k_peer_exchange launch that stores into the peers' mailboxes and waits on
+    its own flags (no RCCL, no host step).  The ranks share the test box's one GPU, so the stores do not cross xGMI here; the
+    protocol (handles, mapping, sequence numbers, parity slots, flag waits between kernels of different processes) is the
+    multi-GPU one.  Against the serial golden step."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 400) + 47 + world
+    mp.spawn(_library_partition_worker, args=(world, port, str(tmp_path), "peer"), nprocs=world, join=True)
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    d = np.load(os.path.join(str(tmp_path), "libdist.npz"))
+    assert int(d["its"]) == int(g["newton_its"][0])
+    assert relerr(d["u"], g["states"][0]) < 1e-8
+    assert np.allclose(d["res"], g["residuals"][0][: len(d["res"])], rtol=1e-4)
+    assert d["kits"].sum() < 700
+    print("peer transport, %d ranks on one card: %d BiCGStab iterations in %.1f ms" % (world, int(d["kits"].sum()), 1e3 * float(d["wall"])))
 
 
 def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
