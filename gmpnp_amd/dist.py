@@ -502,16 +502,34 @@ class PartitionedSolver:
             import torch.distributed as tdist
             if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() == nparts):
                 raise RuntimeError("the peer transport needs an initialised torch.distributed group of %d ranks (to gather the mailbox handles)" % nparts)
+            # Every step is agreed on by ALL ranks before anyone goes on: a rank that cannot allocate or map a mailbox (no peer
+            # access to a GPU, IPC refused) must not leave the others waiting in a collective it never joins.
             mine = create_string_buffer(backend.PEER_HANDLE_BYTES)
-            self._check(self.lib.gmpnp_group_peer_begin(self.devs[0]._h, byref(self._group), mine))
+            err = None
+            try:
+                self._check(self.lib.gmpnp_group_peer_begin(self.devs[0]._h, byref(self._group), mine))
+            except backend.GmpnpError as e:
+                err = e
             dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
-            t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=dev)
+            t = torch.tensor(list(mine.raw) + [0 if err is None else 1], dtype=torch.uint8, device=dev)
             parts = [torch.empty_like(t) for _ in range(nparts)]
             tdist.all_gather(parts, t)      # also the point after which every rank's mailbox exists
-            allh = create_string_buffer(backend.PEER_HANDLE_BYTES * nparts)
-            allh.raw = b"".join(bytes(x.cpu().tolist()) for x in parts)
-            self._check(self.lib.gmpnp_group_peer_connect(self._group, allh))
-            tdist.barrier()                 # nobody stores into a mailbox its owner has not finished setting up... and all are mapped
+            rows = [x.cpu().tolist() for x in parts]
+            if err is None and not any(r[-1] for r in rows):
+                allh = create_string_buffer(backend.PEER_HANDLE_BYTES * nparts)
+                allh.raw = b"".join(bytes(r[:-1]) for r in rows)
+                try:
+                    self._check(self.lib.gmpnp_group_peer_connect(self._group, allh))
+                except backend.GmpnpError as e:
+                    err = e
+            elif err is None:
+                err = RuntimeError("rank(s) %s could not set up a mailbox" % [q for q, r in enumerate(rows) if r[-1]])
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)   # (also: every mailbox is mapped everywhere from here on)
+            if int(flag[0]):
+                self.transport = "peer (failed)"
+                self.close()
+                raise RuntimeError("peer-mailbox transport not available: %s" % (err if err is not None else "another rank could not map a mailbox"))
             return
         if rank is not None and transport == "host":
             self._make_host_transport(rank, nparts)
