@@ -1047,7 +1047,10 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
   if (opts) s->opts = *opts;
   if (s->opts.device_id < 0 || s->opts.device_id >= ndev) return fail(GMPNP_ERR_INVALID, "device_id out of range");
   HIP_TRY(hipSetDevice(s->opts.device_id));
-  if (part) {  // a partitioned handle shares nothing inside a launch and keeps to one stream: the group drives it
+  // a partitioned handle keeps to one stream (no side stream) and the group drives its launches; whether the coarse workgroups
+  // may ride inside the tile launches (peer transport, gmpnp_group.h) is still the caller's choice + the residency proof below
+  const bool part_fused_ok = part && !s->opts.shared_device && s->opts.launch_form != 4;
+  if (part) {
     if (mesh->dim != 3) return fail(GMPNP_ERR_INVALID, "mesh partitions exist for 3D meshes");
     s->opts.shared_device = 1; s->opts.launch_form = 4;
   }
@@ -1167,6 +1170,7 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
       return fail(GMPNP_ERR_INVALID, buf);
     }
     s->fused_half = po.launch_form == 4 ? false : (resident && !po.shared_device && !s->prereduce);
+    if (part) s->fused_half = resident && part_fused_ok;
     // Vector form.  On-the-fly (the tile kernels recompute p / s at their column nodes from four / two vectors: one launch
     // per half-iteration) wins while the operands are cache resident; materialised (k_vec_a / k_vec_b write p / s for all
     // rows first, the tile kernels stage one vector) wins once the gathers cost memory bandwidth: matrix above 768 MB.

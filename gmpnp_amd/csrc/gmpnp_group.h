@@ -99,6 +99,7 @@ struct gmpnp_group {
   int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
   // peer-mailbox transport (gmpnp_group_peer_begin / _connect): one k_peer_exchange launch per collective, no library, no host step
   bool peer = false, peer_connected = false;
+  unsigned* peer_counter = nullptr;                        // arrival counter of k_dist_reduce_exchange (device)
   unsigned char* box = nullptr; size_t box_bytes = 0;   // own mailbox (uncached device memory)
   void* peer_map[kPeerMax] = {};                          // the other ranks' mailboxes as mapped here (IPC)
   PeerArgs pa{};
@@ -306,11 +307,46 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
   if (use_coarse) { rc = group_allreduce(g, [](gmpnp_solver* s) { return s->red_i.p; }, n); if (rc) return rc; }
   rc = group_exchange(g, NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->kr.p; return w; }); if (rc) return rc;   // p_0 = r_0 at the ghost columns
   const dim3 cg(std::max(1, g->dom[0]->t.nagg));
+  const dim3 cg_peer = cg;
   KrylovScalars res = init;
   int k = 0;
   // Per half-iteration and rank THREE launches: [coarse kernel + unpacking of the ghost rows received last], tile kernel,
   // [per-rank sums + packing of the ghost rows to send]; then the all-reduce and the grouped send/recv.
+  // Peer transport: the sums, the ghost rows and their exchange are ONE launch per half-iteration (k_dist_reduce_exchange), the
+  // received rows are in place when it ends: coarse kernel, tile kernel, exchange — 6 launches per iteration (4 where the coarse workgroups ride inside the tile launch), no library call.
+  auto iteration_peer = [&]() -> int {
+    const int par = k & 1;
+    gmpnp_solver* s = g->dom[0];
+    if (!g->peer_connected) return fail(GMPNP_ERR_INVALID, "peer transport: gmpnp_group_peer_connect has not been called");
+    if (*g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
+    const int nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+    // (the received rows are in place and the sums all-reduced when the previous launch ends, so the coarse workgroups can
+    // ride in front of the tile workgroups as on one GPU wherever the whole launch is resident: 4 launches per iteration)
+    const dim3 fg(s->t.nagg + s->t.own_ntiles);
+    if (s->fused_half) hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, (unsigned)(++s->fused_seq));
+    else {
+      hipLaunchKernelGGL((k_coarse_a<NF>), cg_peer, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    }
+    VecListW va{}; va.p[0] = s->kr.p; va.p[1] = s->c.kv[par]; va.p[2] = s->c.kp[par];
+    g->pa.seq++;
+    hipLaunchKernelGGL(k_dist_reduce_exchange, dim3(2 + 3 * n + grid_for(nsn * 3 * NF, 256)), dim3(256), 0, s->stream, s->c, 1, par, s->red_a.p, 2 + 3 * n,
+                       va, 3, NF, (const int32_t*)s->send_nodes.p, nsn, (const int32_t*)s->recv_nodes.p, g->pa, g->peer_counter);
+    if (s->fused_half) hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, (unsigned)(++s->fused_seq));
+    else {
+      hipLaunchKernelGGL((k_coarse_b<NF>), cg_peer, dim3(kCoarseThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    }
+    VecListW vb{}; vb.p[0] = s->ks.p; vb.p[1] = s->kt.p;
+    g->pa.seq++;
+    hipLaunchKernelGGL(k_dist_reduce_exchange, dim3(4 + n + grid_for(nsn * 2 * NF, 256)), dim3(256), 0, s->stream, s->c, 2, par, s->red_b.p, 4 + n,
+                       vb, 2, NF, (const int32_t*)s->send_nodes.p, nsn, (const int32_t*)s->recv_nodes.p, g->pa, g->peer_counter);
+    ++k;
+    HIP_TRY(hipGetLastError());
+    return GMPNP_OK;
+  };
   auto iteration = [&]() -> int {
+    if (g->peer) return iteration_peer();
     const int par = k & 1;
     for (gmpnp_solver* s : g->dom) {
       const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back(), nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
@@ -654,6 +690,8 @@ int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_han
   for (int j = 0; j < a.n_nb; ++j) table[a.nb_rank[j]] = a.recv_ptr[j];
   HIP_TRY(hipMemcpy(g->box + kPeerTableOff, table.data(), kPeerMax * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMalloc((void**)&g->peer_counter, sizeof(unsigned)));
+  HIP_TRY(hipMemset(g->peer_counter, 0, sizeof(unsigned)));
   HIP_TRY(hipHostMalloc((void**)&g->h_peer_err, sizeof(int32_t)));
   *g->h_peer_err = 0;
   a.err = g->h_peer_err;
@@ -695,6 +733,7 @@ void gmpnp_group_destroy(gmpnp_group* g) {
     if (!g->dom.empty()) { (void)hipSetDevice(g->dom[0]->opts.device_id); (void)hipStreamSynchronize(g->dom[0]->stream); }
     for (int q = 0; q < kPeerMax; ++q) if (g->peer_map[q]) (void)hipIpcCloseMemHandle(g->peer_map[q]);
     if (g->box) (void)hipFree(g->box);
+    if (g->peer_counter) (void)hipFree(g->peer_counter);
     if (g->h_peer_err) (void)hipHostFree(g->h_peer_err);
   }
   if (g->h_stage) (void)hipHostFree(g->h_stage);
