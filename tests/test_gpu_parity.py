@@ -1098,3 +1098,57 @@ def test_partitioned_solve_matches_serial(tmp_path, gpu_lib, resident):
     # the converged state agrees tightly
     assert np.allclose(got["res"], g["residuals"][0][:len(got["res"])], rtol=1e-4)
     assert relerr(got["u"], g["states"][0]) < 1e-6
+
+
+def test_pore_equilibrium_is_the_steric_boltzmann_distribution(gpu_lib):
+    """A pin of the 3D transport operator that does not pass through the oracle.  With the reactions and the wall fluxes switched
+    off and no species Dirichlet condition (the Robin exit pulls every species towards 1 on S3, where p = 0), the steady state of
+    the pore is the zero-flux state of 3D:534-750, d ln u_i + z_i dp - d ln(1 - S) = 0, i.e. pointwise
+        u_i = (1 - S) / (1 - S_b) exp(-z_i p),   S = sum_j a_j u_j,
+    WHATEVER the potential looks like.  The potential is made to look like something a P1 mesh of this size resolves: wall
+    value V sin^2(pi z) (no jump against p = 0 on S1 / S3) and a Debye length ten times the physical one (q / 100; the relation
+    does not contain q).  The GPU solution (dt -> infinity) satisfies the relation at every vertex up to the discretisation
+    error (largest on the wall, where the concentrations are steepest), whose rms falls by 2.9 under one uniform refinement; the
+    uncharged species satisfy it to solver accuracy on either mesh."""
+    import copy
+    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+    from gmpnp_amd.params import pore_parameters, utilities_dir
+    from gmpnp_amd.problem import pore_problem
+    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-12,
+                                                          "absolute_tolerance": 1e-10, "relaxation_parameter": 1.0}}
+    V, errs = -1.0, []
+    for refine in (0, 1):
+        prob, _ = pore_problem(pp, mesh, refine=refine)
+        m = copy.deepcopy(prob.model)
+        m.rc0[:] = 0.0; m.rc1[:] = 0.0; m.rc2[:] = 0.0
+        m.wall_flux = np.zeros_like(m.wall_flux)
+        m.inv_dt = 1e-9
+        m.q = m.q / 100.0
+        prob = copy.copy(prob)
+        prob.model = m
+        ns, nv = m.n_species, prob.coords.shape[0]
+        keep = (prob.bc_dofs % (ns + 1)) == ns                     # potential conditions only
+        dofs = prob.bc_dofs[keep]
+        xyz = prob.coords[dofs // (ns + 1)]
+        wall = prob.bc_vals[keep] != 0.0                           # S2 carries the applied voltage, S1 and S3 carry 0
+        assert 0.5 < wall.mean() < 0.9
+        prob.bc_dofs, prob.bc_vals = dofs, np.where(wall, V * np.sin(np.pi * xyz[:, 2]) ** 2, 0.0)
+        z, a = np.asarray(m.z), np.asarray(m.a)
+        u0 = np.tile(np.r_[np.ones(ns), 0.0], nv)
+        with gpu_lib.DeviceSolver(prob) as dev:
+            dev.set_state(u0, u0)
+            st = dev.newton_solve(gpu_lib.newton_options(sp))
+            assert st["converged"]
+            u = dev.get_state().reshape(nv, ns + 1)
+        p, c = u[:, ns], u[:, :ns]
+        assert p.min() == pytest.approx(V, abs=1e-3) and abs(p.max()) < 1e-6
+        S = c @ a
+        expect = ((1.0 - S) / (1.0 - a.sum()))[:, None] * np.exp(-z[None, :] * p[:, None])
+        assert c[:, z > 0].max() > 2.0 and c[:, z < -1.5].min() < 0.2   # a real double layer: cations piled up, CO3-- driven out
+        assert np.abs(c[:, z == 0] / expect[:, z == 0] - 1.0).max() < 1e-6
+        d = c - expect
+        errs.append((np.abs(d).max(), np.sqrt((d ** 2).mean())))
+    print("|u - closed form| (max, rms) on the mesh and on its refinement:", errs)   # 1.8e-2, 2.2e-3 -> 1.2e-2, 7.4e-4
+    assert errs[0][0] < 2e-2 and errs[1][0] < 0.8 * errs[0][0] and errs[1][1] < 0.4 * errs[0][1], errs
