@@ -1265,3 +1265,55 @@ def test_uniform_state_follows_the_published_rate_equations(gpu_lib):
     # ones): the bulk composition of the YAML file is electroneutral to its printed digits only, and the 3e-7 potential that
     # leaves shifts the ions by exp(-z p).
     assert dev_rel.max() < 2e-6 and dev_rel[np.asarray(m.z) == 0].max() < 1e-7
+
+
+def test_wall_and_exit_fluxes_balance_with_the_published_coefficients(gpu_lib):
+    """The boundary terms of the 3D forms (wall Neumann fluxes J_X_wall on ds(2), 3D:474-481, and the exit Robin terms
+    kappa_X (u_X - 1) on ds(3), 3D:484-499) on the GPU against their published coefficients: for a species without reactions,
+    charge or Dirichlet condition (CO, H2) the sum of all test functions turns the steady weak form into the exact discrete balance
+        J_X_wall |S2| + kappa_X int_S3 (u_X - 1) ds (+ the time term, 1e-5 of either at 1 / dt = 1e-9) = 0.
+    J_X_wall and kappa_X are recomputed literally from the YAML files (tests/test_literal_forms.py), the facet areas from the mesh."""
+    import copy
+    from test_literal_forms import PoreConstants
+    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
+    from gmpnp_amd.params import pore_parameters, utilities_dir
+    from gmpnp_amd.problem import pore_problem
+    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    prob, _ = pore_problem(pp, mesh)
+    m = copy.deepcopy(prob.model)
+    m.rc0[:] = 0.0; m.rc1[:] = 0.0; m.rc2[:] = 0.0              # (CO and H2 have no reactions anyway; this keeps the steady solve easy,
+    for X in ("OH", "CO2"):                                       #  as does leaving the ions and CO2 without a wall source)
+        m.wall_flux[list(m.species).index(X)] = 0.0
+    m.inv_dt = 1e-9
+    m.q = m.q / 100.0
+    prob = copy.copy(prob)
+    prob.model = m
+    ns, nv = m.n_species, prob.coords.shape[0]
+    keep = (prob.bc_dofs % (ns + 1)) == ns                          # the potential keeps its conditions, the gases lose theirs
+    prob.bc_dofs, prob.bc_vals = prob.bc_dofs[keep], 0.2 * prob.bc_vals[keep]
+    c = PoreConstants(concentration_elec=0.5, L=10e-9, R=5e-9)
+    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-9,
+                                                          "absolute_tolerance": 1e-9, "relaxation_parameter": 1.0}}
+    u0 = np.tile(np.r_[np.ones(ns), 0.0], nv)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u0, u0)
+        assert dev.newton_solve(gpu_lib.newton_options(sp))["converged"]
+        u = dev.get_state().reshape(nv, ns + 1)
+
+    def area(f):
+        X = prob.coords[f]
+        return 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+
+    a2, a3 = area(prob.wall_facets), area(prob.exit_facets)
+    Xc = prob.coords[prob.cells]
+    vol = np.abs(np.linalg.det(Xc[:, 1:] - Xc[:, :1])) / 6.0
+    assert abs(a2.sum() / (2 * np.pi * 0.5) - 1.0) < 0.02            # the wall of the R / L = 0.5 cylinder (3D/mesh_tests.py:80-85)
+    for X in ("CO", "H2"):
+        i = c.species.index(X)
+        excess = float((a3 * (u[prob.exit_facets, i].mean(axis=1) - 1.0)).sum())      # P1: facet mean = mean of its vertex values
+        stored = m.inv_dt * float((vol * (u[prob.cells, i].mean(axis=1) - 1.0)).sum())   # what is left of the time term at 1 / dt = 1e-9
+        balance = c.J_wall[X] * a2.sum() + c.kappa_exit[X] * excess + stored
+        print(X, "J_wall", c.J_wall[X], "kappa", c.kappa_exit[X], "mean excess at the exit", excess / a3.sum(), "balance", balance)
+        assert abs(excess) > 1e-3 * a3.sum()                        # the species really piles up against the exit
+        assert abs(balance) < 1e-7 * abs(c.J_wall[X] * a2.sum()), (X, balance)
