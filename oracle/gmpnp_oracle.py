@@ -22,7 +22,11 @@ or installable here, and the reference has no tests.  What pins this oracle:
   reference's 20,000-solve staged schedule lands on the recorded digits to 4e-13 ... 1.5e-10 at four voltages
   (profiles/r02/stern_schedule.json, tests/test_gpu_parity.py::test_staged_schedule_reproduces_the_recorded_digits); the
   oracle itself follows the same trajectory (tests/test_oracle_pins.py; 20,000 direct solves are out of its reach).
-* 3D path — **parity unpinned** by reference-held numbers (there are none).  tests/test_literal_forms.py evaluates the
+* 3D path — **parity unpinned** by reference-held numbers (there are none).  What stands in for them: four closed-form cases of
+  the 3D forms (tests/closed_forms.py: zero-flux steric-Boltzmann equilibrium for the transport terms, the Debye-Hueckel Bessel
+  profile for the Poisson coupling, the literal rate equations for reactions + time term, the exact discrete wall / exit flux
+  balance with the literal coefficients), solved by this oracle (tests/test_oracle_pins.py) and by the GPU product
+  (tests/test_gpu_parity.py).  tests/test_literal_forms.py evaluates the
   published 3D/1D integrands and parameter formulas literally (no Model tables) against element_residual_jacobian /
   facet_terms; finite-difference Jacobians, closed-form element integrals vs brute-force quadrature, the steric-Boltzmann
   equilibrium, the wall-area check of 3D/mesh_tests.py:80-85 and the L4 scalars are in tests/test_oracle*.py.  The

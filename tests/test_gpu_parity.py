@@ -1100,103 +1100,40 @@ def test_partitioned_solve_matches_serial(tmp_path, gpu_lib, resident):
     assert relerr(got["u"], g["states"][0]) < 1e-6
 
 
+# ---- closed-form pins of the 3D forms (tests/closed_forms.py): the same four cases run with the oracle in tests/test_oracle_pins.py ----
+TIGHT = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-12,
+                                                         "absolute_tolerance": 1e-10, "relaxation_parameter": 1.0}}
+
+
+def _gpu_steady(gpu_lib, prob, state, sp=TIGHT):
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(state, state)
+        assert dev.newton_solve(gpu_lib.newton_options(sp))["converged"]
+        return dev.get_state()
+
+
 def test_pore_equilibrium_is_the_steric_boltzmann_distribution(gpu_lib):
-    """A pin of the 3D transport operator that does not pass through the oracle.  With the reactions and the wall fluxes switched
-    off and no species Dirichlet condition (the Robin exit pulls every species towards 1 on S3, where p = 0), the steady state of
-    the pore is the zero-flux state of 3D:534-750, d ln u_i + z_i dp - d ln(1 - S) = 0, i.e. pointwise
-        u_i = (1 - S) / (1 - S_b) exp(-z_i p),   S = sum_j a_j u_j,
-    WHATEVER the potential looks like.  The potential is made to look like something a P1 mesh of this size resolves: wall
-    value V sin^2(pi z) (no jump against p = 0 on S1 / S3) and a Debye length ten times the physical one (q / 100; the relation
-    does not contain q).  The GPU solution (dt -> infinity) satisfies the relation at every vertex up to the discretisation
-    error (largest on the wall, where the concentrations are steepest), whose rms falls by 2.9 under one uniform refinement; the
-    uncharged species satisfy it to solver accuracy on either mesh."""
-    import copy
-    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
-    from gmpnp_amd.params import pore_parameters, utilities_dir
-    from gmpnp_amd.problem import pore_problem
-    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
-    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-12,
-                                                          "absolute_tolerance": 1e-10, "relaxation_parameter": 1.0}}
-    V, errs = -1.0, []
+    """closed_forms.boltzmann_case on the GPU, reference mesh and one uniform refinement: the zero-flux steady state of the pore
+    satisfies u_i = (1 - S) / (1 - S_b) exp(-z_i p) at every vertex up to the discretisation error (largest on the wall, where the
+    concentrations are steepest), whose rms falls by 2.9 under refinement; the uncharged species satisfy it to solver accuracy."""
+    import closed_forms as cf
+    errs = []
     for refine in (0, 1):
-        prob, _ = pore_problem(pp, mesh, refine=refine)
-        m = copy.deepcopy(prob.model)
-        m.rc0[:] = 0.0; m.rc1[:] = 0.0; m.rc2[:] = 0.0
-        m.wall_flux = np.zeros_like(m.wall_flux)
-        m.inv_dt = 1e-9
-        m.q = m.q / 100.0
-        prob = copy.copy(prob)
-        prob.model = m
-        ns, nv = m.n_species, prob.coords.shape[0]
-        keep = (prob.bc_dofs % (ns + 1)) == ns                     # potential conditions only
-        dofs = prob.bc_dofs[keep]
-        xyz = prob.coords[dofs // (ns + 1)]
-        wall = prob.bc_vals[keep] != 0.0                           # S2 carries the applied voltage, S1 and S3 carry 0
-        assert 0.5 < wall.mean() < 0.9
-        prob.bc_dofs, prob.bc_vals = dofs, np.where(wall, V * np.sin(np.pi * xyz[:, 2]) ** 2, 0.0)
-        z, a = np.asarray(m.z), np.asarray(m.a)
-        u0 = np.tile(np.r_[np.ones(ns), 0.0], nv)
-        with gpu_lib.DeviceSolver(prob) as dev:
-            dev.set_state(u0, u0)
-            st = dev.newton_solve(gpu_lib.newton_options(sp))
-            assert st["converged"]
-            u = dev.get_state().reshape(nv, ns + 1)
-        p, c = u[:, ns], u[:, :ns]
-        assert p.min() == pytest.approx(V, abs=1e-3) and abs(p.max()) < 1e-6
-        S = c @ a
-        expect = ((1.0 - S) / (1.0 - a.sum()))[:, None] * np.exp(-z[None, :] * p[:, None])
-        assert c[:, z > 0].max() > 2.0 and c[:, z < -1.5].min() < 0.2   # a real double layer: cations piled up, CO3-- driven out
-        assert np.abs(c[:, z == 0] / expect[:, z == 0] - 1.0).max() < 1e-6
-        d = c - expect
-        errs.append((np.abs(d).max(), np.sqrt((d ** 2).mean())))
+        prob, state, check = cf.boltzmann_case(refine)
+        emax, erms, neutral = check(_gpu_steady(gpu_lib, prob, state))
+        assert neutral < 1e-6
+        errs.append((emax, erms))
     print("|u - closed form| (max, rms) on the mesh and on its refinement:", errs)   # 1.8e-2, 2.2e-3 -> 1.2e-2, 7.4e-4
     assert errs[0][0] < 2e-2 and errs[1][0] < 0.8 * errs[0][0] and errs[1][1] < 0.4 * errs[0][1], errs
 
 
 def test_pore_potential_is_the_debye_hueckel_bessel_profile(gpu_lib):
-    """A closed-form pin of the 3D Poisson coupling (3D:752-767: -eps(u) grad p . grad v + q sum_i z_i bulk_i u_i v): for a small wall
-    potential the zero-flux equilibrium linearises to eps_b lap(p) = q (sum_i z_i^2 bulk_i) p, whose solution in a long cylinder with
-    wall value V is p(r) = V I0(kappa r) / I0(kappa R), kappa^2 = q sum_i z_i^2 bulk_i / eps_b.  Mid-pore vertices of L_50_R_5
-    (aspect 10: the ends are five diameters away), reactions and wall fluxes off, q / 100 so that kappa R = O(1) is resolved by
-    the reference mesh.  Checks q, the valences and bulk concentrations in the charge density and eps(u) at the bulk."""
-    import copy
-    from scipy.special import i0
-    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
-    from gmpnp_amd.params import pore_parameters, utilities_dir
-    from gmpnp_amd.problem import pore_problem
-    pp = pore_parameters(concentration_elec=0.5, L=50e-9, R=5e-9)
-    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-12,
-                                                          "absolute_tolerance": 1e-12, "relaxation_parameter": 1.0}}
-    V, errs = -0.005, []
+    """closed_forms.bessel_case on the GPU: p(r) = V I0(kappa r) / I0(kappa R) at the mid-pore vertices of L_50_R_5."""
+    import closed_forms as cf
+    errs = []
     for refine in (0, 1):
-        prob, _ = pore_problem(pp, mesh, refine=refine)
-        m = copy.deepcopy(prob.model)
-        m.rc0[:] = 0.0; m.rc1[:] = 0.0; m.rc2[:] = 0.0
-        m.wall_flux = np.zeros_like(m.wall_flux)
-        m.inv_dt = 1e-9
-        m.q = m.q / 100.0
-        prob = copy.copy(prob)
-        prob.model = m
-        ns, nv = m.n_species, prob.coords.shape[0]
-        keep = (prob.bc_dofs % (ns + 1)) == ns
-        wall = prob.bc_vals[keep] != 0.0
-        prob.bc_dofs, prob.bc_vals = prob.bc_dofs[keep], np.where(wall, V, 0.0)
-        u0 = np.tile(np.r_[np.ones(ns), 0.0], nv)
-        with gpu_lib.DeviceSolver(prob) as dev:
-            dev.set_state(u0, u0)
-            assert dev.newton_solve(gpu_lib.newton_options(sp))["converged"]
-            u = dev.get_state().reshape(nv, ns + 1)
-        z, bulk = np.asarray(m.z), np.asarray(m.bulk)
-        eps_b = m.eps0 + float(np.sum(m.epsc))
-        kappa = np.sqrt(m.q * float(np.sum(z * z * bulk)) / eps_b)
-        r = np.hypot(prob.coords[:, 0], prob.coords[:, 1])
-        R = 0.1                                                        # R / L
-        mid = (prob.coords[:, 2] > 0.3) & (prob.coords[:, 2] < 0.7) & (r < 0.999 * R)
-        assert 0.5 < kappa * R < 5.0 and mid.sum() > 200
-        d = u[mid, ns] / V - i0(kappa * r[mid]) / i0(kappa * R)
-        errs.append((np.abs(d).max(), np.sqrt((d ** 2).mean()), float((u[mid, ns] / V).min())))
+        prob, state, check = cf.bessel_case(refine)
+        errs.append(check(_gpu_steady(gpu_lib, prob, state, cf.sp_tight(1e-12, 1e-12))))
     print("p / V - I0(kappa r) / I0(kappa R) (max, rms), smallest p / V:", errs)
     # 6.5e-2 / 4.1e-2 on the reference mesh, 3.5e-2 / 2.0e-2 after one refinement, p / V = 0.76 on the axis.  (The cross-section of the
     # mesh is a polygon and stays that polygon under red refinement, so the error does not keep falling at second order.)  A factor
@@ -1206,114 +1143,20 @@ def test_pore_potential_is_the_debye_hueckel_bessel_profile(gpu_lib):
 
 
 def test_uniform_state_follows_the_published_rate_equations(gpu_lib):
-    """The homogeneous reactions and the time term of the 3D forms (3D:505-534) end to end on the GPU against an independent
-    8-unknown solve: a spatially uniform, electroneutral state without wall or exit fluxes stays uniform, and one backward-Euler
-    step is, at every vertex, (u_X - u_X^n) / del_t = R_X(u) with the published rate expressions — evaluated here literally from the
-    YAML files (tests/test_literal_forms.py: named rate constants, u_X * bulk_conc[X], scale_R, del_t = 1e-3 / time_constant) and
-    solved with SciPy.  Start: the bulk with twice the protons (and the hydroxide that keeps it neutral) and 50 % more dissolved CO2."""
-    import copy
-    from scipy.optimize import fsolve
-    from test_literal_forms import PoreConstants, production_rates
-    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
-    from gmpnp_amd.params import pore_parameters, utilities_dir
-    from gmpnp_amd.problem import pore_problem
-    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
-    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-    prob, _ = pore_problem(pp, mesh)
-    m = copy.deepcopy(prob.model)
-    m.wall_flux = np.zeros_like(m.wall_flux)
-    m.exit_kappa = np.zeros_like(m.exit_kappa)
-    prob = copy.copy(prob)
-    prob.model = m
-    ns, nv = m.n_species, prob.coords.shape[0]
-    keep = (prob.bc_dofs % (ns + 1)) == ns
-    prob.bc_dofs, prob.bc_vals = prob.bc_dofs[keep], np.zeros(int(keep.sum()))      # p = 0 on the whole boundary, nothing else
-    c = PoreConstants(concentration_elec=0.5, L=10e-9, R=5e-9)
-    assert list(m.species) == c.species
-    un = np.ones(ns)
-    iH, iOH, iCO2 = (c.species.index(x) for x in ("H", "OH", "CO2"))
-    un[iCO2] = 1.5
-    un[iH] = 2.0                                             # twice the protons ...
-    un[iOH] = 1.0 + c.bulk["H"] / c.bulk["OH"]               # ... and the hydroxide that keeps the state electroneutral
-
-    def step(u):
-        R = production_rates(c, dict(zip(c.species, u)))
-        return (u - un) / c.del_t - np.array([R[x] for x in c.species])
-
-    u1 = fsolve(step, un, xtol=1e-13)
-    for _ in range(3):                                                   # polish: Newton with a finite-difference Jacobian
-        J = np.empty((ns, ns))
-        for j in range(ns):
-            e = np.zeros(ns); e[j] = 1e-7 * max(1.0, abs(u1[j]))
-            J[:, j] = (step(u1 + e) - step(u1 - e)) / (2 * e[j])
-        u1 = u1 - np.linalg.solve(J, step(u1))
-    assert np.abs(step(u1)).max() < 1e-9 * np.abs((u1 - un) / c.del_t).max()
-    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-13,
-                                                          "absolute_tolerance": 1e-11, "relaxation_parameter": 1.0}}
-    state = np.tile(np.r_[un, 0.0], nv)
-    with gpu_lib.DeviceSolver(prob) as dev:
-        dev.set_state(state, state)
-        assert dev.newton_solve(gpu_lib.newton_options(sp))["converged"]
-        u = dev.get_state().reshape(nv, ns + 1)
-    moved = np.abs(u1 - un) / un
-    print("change in the step:", moved)
-    assert moved[iH] > 0.05 and moved[iCO2] > 1e-9          # the protons recombine within the step; CO2 hydration barely starts
-    assert np.abs(u[:, ns]).max() < 1e-6                                                    # neutral stays neutral: no potential
-    dev_rel = np.abs(u[:, :ns] / u1[None, :] - 1.0).max(0)
-    print("relative deviation from the 8-unknown solve per species:", dev_rel, "change in the step:", moved)
-    # H moves by 16 %, OH by 0.24 % in the step; the GPU agrees with the 8-unknown solve to 3e-7 (charged species) / 2e-8 (neutral
-    # ones): the bulk composition of the YAML file is electroneutral to its printed digits only, and the 3e-7 potential that
-    # leaves shifts the ions by exp(-z p).
-    assert dev_rel.max() < 2e-6 and dev_rel[np.asarray(m.z) == 0].max() < 1e-7
+    """closed_forms.rates_case on the GPU: one backward-Euler step of a uniform electroneutral state against the literal
+    8-unknown solve.  H moves by 16 %, OH by 0.24 % in the step; the GPU agrees to 3e-7 (charged species) / 2e-8 (neutral ones):
+    the bulk composition of the YAML file is electroneutral to its printed digits only, and the 3e-7 potential that leaves
+    shifts the ions by exp(-z p)."""
+    import closed_forms as cf
+    prob, state, check = cf.rates_case()
+    dev_rel, neutral_rel, pmax = check(_gpu_steady(gpu_lib, prob, state, cf.sp_tight(1e-13, 1e-11)))
+    assert pmax < 1e-6 and dev_rel < 2e-6 and neutral_rel < 1e-7
 
 
 def test_wall_and_exit_fluxes_balance_with_the_published_coefficients(gpu_lib):
-    """The boundary terms of the 3D forms (wall Neumann fluxes J_X_wall on ds(2), 3D:474-481, and the exit Robin terms
-    kappa_X (u_X - 1) on ds(3), 3D:484-499) on the GPU against their published coefficients: for a species without reactions,
-    charge or Dirichlet condition (CO, H2) the sum of all test functions turns the steady weak form into the exact discrete balance
-        J_X_wall |S2| + kappa_X int_S3 (u_X - 1) ds (+ the time term, 1e-5 of either at 1 / dt = 1e-9) = 0.
-    J_X_wall and kappa_X are recomputed literally from the YAML files (tests/test_literal_forms.py), the facet areas from the mesh."""
-    import copy
-    from test_literal_forms import PoreConstants
-    from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
-    from gmpnp_amd.params import pore_parameters, utilities_dir
-    from gmpnp_amd.problem import pore_problem
-    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
-    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-    prob, _ = pore_problem(pp, mesh)
-    m = copy.deepcopy(prob.model)
-    m.rc0[:] = 0.0; m.rc1[:] = 0.0; m.rc2[:] = 0.0              # (CO and H2 have no reactions anyway; this keeps the steady solve easy,
-    for X in ("OH", "CO2"):                                       #  as does leaving the ions and CO2 without a wall source)
-        m.wall_flux[list(m.species).index(X)] = 0.0
-    m.inv_dt = 1e-9
-    m.q = m.q / 100.0
-    prob = copy.copy(prob)
-    prob.model = m
-    ns, nv = m.n_species, prob.coords.shape[0]
-    keep = (prob.bc_dofs % (ns + 1)) == ns                          # the potential keeps its conditions, the gases lose theirs
-    prob.bc_dofs, prob.bc_vals = prob.bc_dofs[keep], 0.2 * prob.bc_vals[keep]
-    c = PoreConstants(concentration_elec=0.5, L=10e-9, R=5e-9)
-    sp = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-9,
-                                                          "absolute_tolerance": 1e-9, "relaxation_parameter": 1.0}}
-    u0 = np.tile(np.r_[np.ones(ns), 0.0], nv)
-    with gpu_lib.DeviceSolver(prob) as dev:
-        dev.set_state(u0, u0)
-        assert dev.newton_solve(gpu_lib.newton_options(sp))["converged"]
-        u = dev.get_state().reshape(nv, ns + 1)
-
-    def area(f):
-        X = prob.coords[f]
-        return 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
-
-    a2, a3 = area(prob.wall_facets), area(prob.exit_facets)
-    Xc = prob.coords[prob.cells]
-    vol = np.abs(np.linalg.det(Xc[:, 1:] - Xc[:, :1])) / 6.0
-    assert abs(a2.sum() / (2 * np.pi * 0.5) - 1.0) < 0.02            # the wall of the R / L = 0.5 cylinder (3D/mesh_tests.py:80-85)
-    for X in ("CO", "H2"):
-        i = c.species.index(X)
-        excess = float((a3 * (u[prob.exit_facets, i].mean(axis=1) - 1.0)).sum())      # P1: facet mean = mean of its vertex values
-        stored = m.inv_dt * float((vol * (u[prob.cells, i].mean(axis=1) - 1.0)).sum())   # what is left of the time term at 1 / dt = 1e-9
-        balance = c.J_wall[X] * a2.sum() + c.kappa_exit[X] * excess + stored
-        print(X, "J_wall", c.J_wall[X], "kappa", c.kappa_exit[X], "mean excess at the exit", excess / a3.sum(), "balance", balance)
-        assert abs(excess) > 1e-3 * a3.sum()                        # the species really piles up against the exit
-        assert abs(balance) < 1e-7 * abs(c.J_wall[X] * a2.sum()), (X, balance)
+    """closed_forms.flux_case on the GPU: J_X_wall |S2| + kappa_X int_S3 (u_X - 1) ds + (time term) = 0 for CO and H2, closed to
+    1e-11 of 18."""
+    import closed_forms as cf
+    prob, state, check = cf.flux_case()
+    for X, (balance, scale, excess) in check(_gpu_steady(gpu_lib, prob, state, cf.sp_tight(1e-9, 1e-9))).items():
+        assert excess > 1e3 and abs(balance) < 1e-7 * scale, (X, balance, scale)

@@ -113,3 +113,49 @@ def test_oracle_field_ohp_near_recorded_value():
     field_ohp = fld[int(np.argmin(mesh.coords[:, 0]))] * ep.thermal_voltage / ep.L_n * 1e-9
     assert abs(field_ohp / -0.08032108300135771 - 1.0) < 0.025
     assert field_ohp > -0.08032108300135771  # approaching from below in magnitude
+
+
+# ---- the oracle against the closed-form cases of the 3D forms (tests/closed_forms.py; the GPU runs the same cases on the reference
+# meshes and their refinements, the oracle on small generated cylinders it solves in seconds) ------------------------------------------
+def _oracle_steady(prob, state, rtol=1e-12, atol=1e-10):
+    u, st = O.newton_solve(prob, state.copy(), state.copy(), relaxation_parameter=1.0, relative_tolerance=rtol, absolute_tolerance=atol,
+                           maximum_iterations=50)
+    assert st.converged
+    return u
+
+
+def test_oracle_pore_equilibrium_is_the_steric_boltzmann_distribution():
+    """Transport terms of the 3D forms in the ORACLE against u_i = (1 - S) / (1 - S_b) exp(-z_i p): two generated cylinders, the
+    error of the charged species falls with the mesh width, the uncharged ones satisfy the relation to solver accuracy."""
+    import closed_forms as cf
+    errs = []
+    for coarse in ((3, 6), (6, 12)):
+        prob, state, check = cf.boltzmann_case(0, V=-0.5, coarse=coarse)
+        emax, erms, neutral = check(_oracle_steady(prob, state))
+        assert neutral < 1e-6
+        errs.append((emax, erms))
+    assert errs[1][1] < 0.45 * errs[0][1] and errs[1][1] < 3e-3, errs
+
+
+def test_oracle_uniform_state_follows_the_published_rate_equations():
+    """Reactions + time term of the 3D forms in the ORACLE against the literal 8-unknown backward-Euler solve (mesh independent)."""
+    import closed_forms as cf
+    prob, state, check = cf.rates_case(coarse=(3, 6))
+    dev_rel, neutral_rel, pmax = check(_oracle_steady(prob, state, 1e-13, 1e-11))
+    assert pmax < 1e-6 and dev_rel < 2e-6 and neutral_rel < 1e-7
+
+
+def test_oracle_wall_and_exit_fluxes_balance_with_the_published_coefficients():
+    """Wall Neumann / exit Robin terms of the 3D forms in the ORACLE: exact discrete flux balance with the literal coefficients."""
+    import closed_forms as cf
+    prob, state, check = cf.flux_case(coarse=(3, 6))
+    for X, (balance, scale, excess) in check(_oracle_steady(prob, state, 1e-9, 1e-9)).items():
+        assert excess > 1e3 and abs(balance) < 1e-7 * scale, (X, balance, scale)
+
+
+def test_oracle_pore_potential_is_the_debye_hueckel_bessel_profile():
+    """Poisson coupling of the 3D forms in the ORACLE: p = V I0(kappa r) / I0(kappa R) at mid-pore of a generated aspect-0.1 cylinder."""
+    import closed_forms as cf
+    prob, state, check = cf.bessel_case(0, coarse=(4, 24))
+    emax, erms, axis = check(_oracle_steady(prob, state, 1e-12, 1e-12))
+    assert axis < 0.9 and erms < 5e-2 and emax < 8e-2, (emax, erms, axis)
