@@ -209,13 +209,17 @@ def slab_permutation(coords: np.ndarray, cells: np.ndarray, window: int = 224) -
     return out.astype(np.int32)
 
 
+_PC_NOTED = set()
+
+
 def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptions:
     """Translate the reference's ``solver_parameters`` dict (3D:789-798, 1D:357-364) + [3P] DOLFIN
     defaults.  Direct solvers ('default', 'lu', 'mumps', 'umfpack', 'superlu', 'petsc') map to the
     "exact-equivalent" two-level BiCGStab at 1e-10 relative residual (a 3D solve that does not converge falls back
     to the block-banded LU inside the library; ``GMPNP_3D_DIRECT=1`` maps them to that LU from the start, the literal
     reading of 'mumps'); 'band_lu' asks for the LU by name; 'bicgstab' honours ``preconditioner``
-    ('jacobi' | anything else -> two-level) and a ``krylov_solver`` sub-dict."""
+    ('jacobi' -> node-block Jacobi; 'default', 'ilu', the AMG names -> two-level, with a warning; 'none' / unknown: refused) and a
+    ``krylov_solver`` sub-dict."""
     sp = dict(solver_parameters or {})
     if sp.get("nonlinear_solver", "newton") != "newton":
         raise RuntimeError("nonlinear_solver %r is not available" % sp.get("nonlinear_solver"))
@@ -236,7 +240,22 @@ def newton_options(solver_parameters: dict = None, dim: int = 3) -> CNewtonOptio
         o.linear_solver = LINEAR_BLOCK_TRIDIAGONAL if dim == 1 else LINEAR_BAND_LU
         o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-10))
     elif lin == "bicgstab":
-        o.linear_solver = LINEAR_JACOBI if ns.get("preconditioner", "default") == "jacobi" else LINEAR_TWOLEVEL
+        # [3P] preconditioner names of the PETSc backend.  Node-block Jacobi is built as such; every name that asks for something
+        # stronger than Jacobi (DOLFIN's 'default' = ILU, 'ilu', 'icc', 'sor', the AMG family) gets the one stronger
+        # preconditioner this backend has — node-block Jacobi + slab coarse space: a triangular solve per application would
+        # serialise the GPU — and says so once; 'none' and unknown names are refused rather than silently replaced.
+        pc = ns.get("preconditioner", "default")
+        if pc in ("jacobi", "bjacobi"):
+            o.linear_solver = LINEAR_JACOBI
+        elif pc in ("default", "ilu", "icc", "sor", "amg", "hypre_amg", "petsc_amg", "ml_amg", "hypre_euclid", "hypre_parasails"):
+            o.linear_solver = LINEAR_TWOLEVEL
+            if pc != "default" and pc not in _PC_NOTED:
+                _PC_NOTED.add(pc)
+                import warnings
+                warnings.warn("preconditioner %r is served by the two-level preconditioner (node-block Jacobi + slab coarse space) "
+                              "of the MI355X backend" % pc, stacklevel=2)
+        else:
+            raise RuntimeError("preconditioner %r is not available in the MI355X backend (jacobi, or default / ilu / amg -> two-level)" % pc)
         o.krylov_relative_tolerance = float(ks.get("relative_tolerance", 1e-6))
     else:
         raise RuntimeError("linear_solver %r is not available in the MI355X backend" % lin)

@@ -83,6 +83,12 @@ def test_newton_options_translation(backend):
     j = backend.newton_options({"newton_solver": {"linear_solver": "bicgstab", "preconditioner": "jacobi",
                                                   "krylov_solver": {"relative_tolerance": 1e-8}}})
     assert j.linear_solver == backend.LINEAR_JACOBI and j.krylov_relative_tolerance == 1e-8
+    with pytest.warns(UserWarning, match="two-level"):   # 'ilu' is served by the two-level preconditioner, and says so
+        i = backend.newton_options({"newton_solver": {"linear_solver": "bicgstab", "preconditioner": "ilu"}})
+    assert i.linear_solver == backend.LINEAR_TWOLEVEL and i.krylov_relative_tolerance == 1e-6
+    for pc in ("none", "no_such_preconditioner"):
+        with pytest.raises(RuntimeError):
+            backend.newton_options({"newton_solver": {"linear_solver": "bicgstab", "preconditioner": pc}})
     with pytest.raises(RuntimeError):
         backend.newton_options({"newton_solver": {"linear_solver": "cholmod"}})
     with pytest.raises(RuntimeError):
