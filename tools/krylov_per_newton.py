@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""BiCGStab iterations per Newton iteration over the bench window (first / second / third / later solves of a time step)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gmpnp_amd.pore3d import PoreRun
 run = PoreRun(num_steps=50, concentration_elec=0.5, L=50e-9, R=5e-9)
 tot=0
