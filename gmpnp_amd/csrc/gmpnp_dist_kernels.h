@@ -49,9 +49,10 @@ __device__ __forceinline__ void dist_reduce_block(const Ctx& c, int phase, int p
     count = c.ntiles; stride = 1;
   } else {
     const int q = o - nscal, w = q / n, d = q - w * n;
+    const int nf = n / c.nagg, ag = d / nf;   // part[aggregate][slot][field] (cpart_index)
     p = (phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
-         : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par])) + d;
-    count = c.tile_slots; stride = n;
+         : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par])) + (size_t)ag * c.tile_slots * nf + (d - ag * nf);
+    count = c.tile_slots; stride = nf;
   }
   double v[1] = {0.0};
   for (int i0 = t; i0 < count; i0 += 8 * 256) {   // eight independent requests per thread and trip

@@ -896,7 +896,13 @@ struct PartialSums {
   }
 };
 
-// Restriction partials part[slot][n] of ONE aggregate g: 8 lanes per (array q, field f) sum the slots of coarse dof
+// Layout of the per-tile restriction partials: part[aggregate][slot][field] — the tile_slots x NF values of ONE aggregate
+// contiguous (38 cache lines for 66 slots), because its coarse workgroup is the one that reads them and does so on every
+// tile's critical path.  (part[slot][coarse dof] put an aggregate's 72-byte pieces 576 bytes apart: 66-132 lines per array.)
+__device__ __forceinline__ size_t cpart_index(const Ctx& c, int slot, int agg, int f, int nf) {
+  return ((size_t)agg * c.tile_slots + slot) * nf + f;
+}
+// Restriction partials of ONE aggregate g: 8 lanes per (array q, field f) sum the slots of coarse dof
 // g*NF+f; the workgroup of aggregate g needs nothing else of the partial arrays.
 template <int K, int NF>
 struct AggSlotSums {
@@ -909,9 +915,9 @@ struct AggSlotSums {
     base = part[0];
 #pragma unroll
     for (int z = 1; z < K; ++z) base = (q == z) ? part[z] : base;
-    base += (size_t)g * NF + f;
+    base += (size_t)g * slots * NF + f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = base[(size_t)min(l + L * u, slots - 1) * n];
+    for (int u = 0; u < U; ++u) r[u] = base[(size_t)min(l + L * u, slots - 1) * NF];
   }
   // lds[K*NF]; the caller synchronises
   __device__ inline void to_lds(double* lds, int n, int slots) {
@@ -922,7 +928,7 @@ struct AggSlotSums {
     for (int s0 = l + L * U; s0 < slots; s0 += 4 * L) {  // large meshes only
       double w[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) w[u] = base[(size_t)min(s0 + u * L, slots - 1) * n];
+      for (int u = 0; u < 4; ++u) w[u] = base[(size_t)min(s0 + u * L, slots - 1) * NF];
 #pragma unroll
       for (int u = 0; u < 4; ++u) v += (s0 + u * L < slots) ? w[u] : 0.0;
     }
@@ -1406,7 +1412,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[which][q][il * NF + f];
     double* dstp = which == 0 ? c.cpart_v[par] : (which == 1 ? c.cpart_r[par] : c.cpart_p[par]);
-    dstp[(size_t)rec.slot * n + rec.agg * NF + f] = sacc;
+    dstp[cpart_index(c, rec.slot, rec.agg, f, NF)] = sacc;
   } else if (t == 64) {
     double a0 = 0.0, a1 = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
@@ -1516,7 +1522,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     double sacc = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[q][il * NF + t];
-    c.cpart_t[(size_t)rec.slot * n + rec.agg * NF + t] = sacc;
+    c.cpart_t[cpart_index(c, rec.slot, rec.agg, t, NF)] = sacc;
   } else if (t == 64) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1665,7 +1671,7 @@ __global__ __launch_bounds__(kVecBlock) void k_restrict(const Ctx c, const doubl
     double sacc = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += lv[q * 64 + il * NF + t];
-    part[(size_t)c.tile_slot[tile] * c.ncoarse + c.tile_agg[tile] * NF + t] = sacc;
+    part[cpart_index(c, c.tile_slot[tile], c.tile_agg[tile], t, NF)] = sacc;
   }
 }
 
@@ -1690,7 +1696,7 @@ __global__ __launch_bounds__(kKrylovThreads) void k_minv_apply(const Ctx c, cons
       for (int q0 = 0; q0 < c.tile_slots; q0 += 8) {
         double w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = part[(size_t)min(q0 + u, c.tile_slots - 1) * c.ncoarse + t];
+        for (int u = 0; u < 8; ++u) w[u] = part[cpart_index(c, min(q0 + u, c.tile_slots - 1), t / NF, t - (t / NF) * NF, NF)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) sacc += (q0 + u < c.tile_slots) ? w[u] : 0.0;
       }
@@ -1833,7 +1839,7 @@ __global__ __launch_bounds__(kVecBlock) void k_krylov_init(const Ctx c, const do
     double sacc = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += lv[q * 64 + il * NF + t];
-    part[(size_t)c.tile_slot[tile] * c.ncoarse + c.tile_agg[tile] * NF + t] = sacc;
+    part[cpart_index(c, c.tile_slot[tile], c.tile_agg[tile], t, NF)] = sacc;
   }
 }
 __global__ void k_copy2(double* __restrict__ a, double* __restrict__ b, const double* __restrict__ src, int n) {
