@@ -1080,6 +1080,10 @@ constexpr int kStagePre = 2;  // staged x entries per thread requested up front 
 // compiler sinks every request below this branch, i.e. behind the scalar round trip that fetches the flag.
 #define GMPNP_EXIT_IF_DONE(flag, keep_expr) do { if (flag) { if (c.ndof < 0) c.yc[0] = (keep_expr); return; } } while (0)
 // ---- in-launch hand-over from the coarse workgroups to the tile workgroups (fused launch form) ---------------------
+#ifndef GMPNP_FLAG_COPIES
+#define GMPNP_FLAG_COPIES 8
+#endif
+constexpr int kFlagCopies = GMPNP_FLAG_COPIES;   // copies of the flag row (power of two, <= 64: 16 words apart, Ctx::ticket holds 16 * 66)
 // Hand-over flags: coarse workgroup g raises flag g (one cache line holds all of them) to the sequence number of the
 // launch; lane g of a tile workgroup's first wave polls flag g and the wave leaves the loop on a unanimous vote.  No
 // counter, no read-modify-write, no second hop: the consumers see a coarse workgroup's flag one store after its payload.
@@ -1091,7 +1095,9 @@ __device__ __forceinline__ void publish_ticket(const Ctx& c, unsigned seq, int g
     // XCD and the consumers' acquire would invalidate theirs 66 times per launch (measured: +7 us per launch).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(c.ticket + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // eight copies of the flag row (one 64-byte line each): a tile polls the copy of its XCD's number, so that 66 instead of 529
+    // workgroups hammer one line
+    if (threadIdx.x < kFlagCopies) __hip_atomic_store(c.ticket + threadIdx.x * 16 + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 // progress / verdict for the host's spin loop (HostPoll): write-through to system memory, no fence
@@ -1110,7 +1116,7 @@ __device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
     int ok = 1;
     const unsigned long long t0 = wall_clock64();
     while (true) {
-      const unsigned f = mine ? __hip_atomic_load(c.ticket + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
+      const unsigned f = mine ? __hip_atomic_load(c.ticket + (blockIdx.x & (kFlagCopies - 1)) * 16 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seq;
       if (__all(f >= seq)) break;
       // 2 s at 100 MHz.  The flags cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
       // budget only has to outlast a time slice taken by another process sharing the GPU.  Ends the solve (later
