@@ -1359,12 +1359,20 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {  // scalars and coarse products of THIS launch's coarse workgroups
     if (!wait_ticket(c, target)) return;
-    omega = load_coherent(&sc->omega); beta = load_coherent(&sc->beta);
+    // the two scalars: ONE wave asks (one request instead of eight per tile on the line every tile reads at this moment), the
+    // others get them through LDS behind the barrier that follows anyway
+    __shared__ double hand[2];
+    double w0 = 0.0, b0 = 0.0;
+    if (wv == 0) { w0 = load_coherent(&sc->omega); b0 = load_coherent(&sc->beta); }
     tcs.template load_values<true>(c);
+    if (t == 0) { hand[0] = w0; hand[1] = b0; }
+    if (c.use_coarse) tcs.to_lds(c, ycl);
+    __syncthreads();
+    omega = hand[0]; beta = hand[1];
   }
   GMPNP_STAMP(1);
   const bool uc = c.use_coarse != 0;
-  if (uc) { tcs.to_lds(c, ycl); __syncthreads(); }
+  if (!FUSED && uc) { tcs.to_lds(c, ycl); __syncthreads(); }
   GMPNP_STAMP(2);
   // stage x = p_new + P yc for the tile's column nodes
 #pragma unroll
@@ -1483,8 +1491,14 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {
     if (!wait_ticket(c, target)) return;
-    dn = (int)load_coherent(&sc->done_next); alpha = load_coherent(&sc->alpha);
-    if (!dn) tcs.template load_values<true>(c);
+    __shared__ double hand[2];   // see bicg_a_body
+    double d0 = 0.0, a0 = 0.0;
+    if (wv == 0) { d0 = load_coherent(&sc->done_next); a0 = load_coherent(&sc->alpha); }
+    tcs.template load_values<true>(c);
+    if (t == 0) { hand[0] = d0; hand[1] = a0; }
+    if (c.use_coarse) tcs.to_lds(c, ycl);
+    __syncthreads();
+    dn = (int)hand[0]; alpha = hand[1];
   }
   if (dn) {
     if (tile == c.tile0 && t == 0) {
@@ -1494,7 +1508,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     return;
   }
   const bool uc = c.use_coarse != 0;
-  if (uc) { tcs.to_lds(c, ycl); __syncthreads(); }
+  if (!FUSED && uc) { tcs.to_lds(c, ycl); __syncthreads(); }
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
