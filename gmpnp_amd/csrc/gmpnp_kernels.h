@@ -946,11 +946,12 @@ struct TileCoarse {
   static constexpr int ROWS = kTileAggs * NF;
   static_assert(ROWS * 8 <= kKrylovThreads, "one pass: 8 lanes per coarse dof of the tile");
   double a0, a1;
-  int d;
+  int d, nrows;
   __device__ inline void load_index(const Ctx& c, int tile) {  // straight-line: requests only
     const int t = threadIdx.x, rc = min(t >> 3, ROWS - 1);
     const int ag = c.tile_aggs[tile * kTileAggs + rc / NF];
     d = ag * NF + (rc - (rc / NF) * NF);
+    nrows = c.tile_nagg[tile] * NF;   // coarse dofs the tile really prolongs from (the other slots repeat aggregate 0)
   }
   template <bool COHERENT>
   __device__ inline void load_values(const Ctx& c) {
@@ -958,8 +959,13 @@ struct TileCoarse {
     const double* p0 = c.yc + (size_t)min(l, c.nagg - 1) * n + d;
     const double* p1 = c.yc + (size_t)min(l + 8, c.nagg - 1) * n + d;
     if (COHERENT) {  // written by coarse workgroups of the same launch: agent-scope loads, no cached copy
-      a0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // Behind the hand-over every tile asks for these lines in the same microsecond: only the requests that carry something —
+      // the tile's real aggregates (2-3 of the kTileAggs slots), and the second column-block half only with more than 8 blocks.
+      a0 = 0.0; a1 = 0.0;
+      if ((int)(threadIdx.x >> 3) < nrows) {
+        a0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c.nagg > 8) a1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else { a0 = *p0; a1 = *p1; }
   }
   // ycl[kMaxCoarse], indexed by the global coarse dof; the caller synchronises
@@ -967,7 +973,7 @@ struct TileCoarse {
     const int t = threadIdx.x, l = t & 7;
     double a = ((l < c.nagg) ? a0 : 0.0) + ((l + 8 < c.nagg) ? a1 : 0.0);
     a = group8_sum_to_last(a);
-    if (l == 7 && (t >> 3) < ROWS) ycl[d] = a;
+    if (l == 7 && (t >> 3) < nrows) ycl[d] = a;   // (the padding slots repeat aggregate 0: they must not overwrite its sums)
   }
 };
 
