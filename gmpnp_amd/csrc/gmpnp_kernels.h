@@ -1286,6 +1286,10 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
   publish_ticket<FUSED>(c, target, g);
 }
 
+// Results of a tile kernel (its rows of the new vectors, its partial sums) are read by the NEXT launch, on other XCDs as well:
+// stored write-through, so that the write-back of the XCD's L2 at the end of the kernel finds nothing left to do (k_half_a
+// 10.68 -> 10.52 us, k_half_b 9.95 -> 9.66 us; non-temporal stores instead: slower than plain ones).
+__device__ __forceinline__ void st_out(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // ---- fused half-iterations ------------------------------------------------------------------------------------
 // MAT ("materialised"): p_k (resp. s_k) was written for ALL rows by k_vec_a (k_vec_b) in front of this launch, together with
 // the own-row updates of y and r; the tile stages ONE vector at its column nodes instead of recomputing p from four (s from
@@ -1412,14 +1416,14 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
       else {
         if (first) { rn = own_s; pn = rn; }
         else {
-          c.ky[own_r] = own_y + alpha * own_p + omega * own_s;
+          st_out(&c.ky[own_r], own_y + alpha * own_p + omega * own_s);
           rn = own_s - omega * own_t;
-          c.kr[own_r] = rn;
+          st_out(&c.kr[own_r], rn);
           pn = rn + beta * (own_p - omega * own_v);
         }
-        c.kp[par][own_r] = pn;
+        st_out(&c.kp[par][own_r], pn);
       }
-      c.kv[par][own_r] = tot;
+      st_out(&c.kv[par][own_r], tot);
     }
     outv[0][sl][lane] = tot; outv[1][sl][lane] = rn; outv[2][sl][lane] = pn;
     const double d0 = wave_sum(own_rh * tot), d1 = wave_sum(rn * rn);
@@ -1432,11 +1436,11 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[which][q][il * NF + f];
     double* dstp = which == 0 ? c.cpart_v[par] : (which == 1 ? c.cpart_r[par] : c.cpart_p[par]);
-    dstp[cpart_index(c, rec.slot, rec.agg, f, NF)] = sacc;
+    st_out(&dstp[cpart_index(c, rec.slot, rec.agg, f, NF)], sacc);
   } else if (t == 64) {
     double a0 = 0.0, a1 = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
-    c.part_a[tile] = a0; c.part_rr[tile] = a1;
+    st_out(&c.part_a[tile], a0); st_out(&c.part_rr[tile], a1);
   }
 #ifdef GMPNP_TIMING
   __syncthreads();
@@ -1536,8 +1540,8 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
       for (int q = 0; q < NW; ++q) tt += red[sl * NW + q][lane];
       sv = MAT ? own_r_ : own_r_ - alpha * own_v;
-      if (!MAT) c.ks[own_r] = sv;
-      c.kt[own_r] = tt;
+      if (!MAT) st_out(&c.ks[own_r], sv);
+      st_out(&c.kt[own_r], tt);
     }
     outv[sl][lane] = tt;
     const double d0 = wave_sum(tt * sv), d1 = wave_sum(tt * tt), d2 = wave_sum(own_rh * sv), d3 = wave_sum(own_rh * tt);
@@ -1548,13 +1552,13 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
     double sacc = 0.0;
     for (int q = 0; q < kSlicesPerTile; ++q)
       for (int il = 0; il < kWave / NF; ++il) sacc += outv[q][il * NF + t];
-    c.cpart_t[cpart_index(c, rec.slot, rec.agg, t, NF)] = sacc;
+    st_out(&c.cpart_t[cpart_index(c, rec.slot, rec.agg, t, NF)], sacc);
   } else if (t == 64) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       double a0 = 0.0;
       for (int q = 0; q < kSlicesPerTile; ++q) a0 += dpart[q][m];
-      c.part_b[(size_t)m * c.ntiles + tile] = a0;
+      st_out(&c.part_b[(size_t)m * c.ntiles + tile], a0);
     }
     if (tile == c.tile0) { sc->iters = k + 1; poll_store(&c.poll->iters, k + 1); }
   }
