@@ -124,7 +124,7 @@ struct gmpnp_solver {
   // block-tridiagonal direct solver (1D): cyclic-reduction pyramid
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
   // block-banded LU (3D): direct solver / fallback of the Krylov solve; storage is allocated on first use
-  DevBuf<double> lu_band, lu_dinv, lu_y; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
+  DevBuf<double> lu_band, lu_dinv, lu_y, lu_part; DevBuf<int32_t> lu_pos, lu_node; BandLU lu{}; bool lu_ready = false;
   // asynchronous coarse refresh: the Galerkin product + inverse of THIS iteration's matrix run on a side stream while
   // BiCGStab uses the inverse built from the previous iteration's matrix; adopted at the next set-up (double buffer)
   hipStream_t stream2 = nullptr; hipEvent_t ev_mat = nullptr, ev_chain = nullptr, ev_jac = nullptr, ev_dots = nullptr;
@@ -726,19 +726,17 @@ template <int NF>
 int band_prepare(gmpnp_solver* s) {
   if (s->lu_ready) return GMPNP_OK;
   const Topology& t = s->t;
-  const int n = t.nv, b = t.lu_band;
+  const int n = t.nv, b = std::max(t.lu_band, kBandPanel - 1);   // the substitution's panel triangle lies inside the stored band
   const double gb = (double)n * (2.0 * b + 1.0) * NF * NF * sizeof(double) / 1e9;
   char buf[200];
   if (gb > s->lu_max_gb) {
     snprintf(buf, sizeof buf, "block-banded LU needs %.1f GB (%d node blocks, band %d), above gmpnp_options_t.band_lu_max_gb = %.1f", gb, n, b, s->lu_max_gb);
     return fail(GMPNP_ERR_INVALID, buf);
   }
-  const size_t ring = (size_t)(b + 1) * NF * sizeof(double);
-  if (ring > 150u * 1024u) return fail(GMPNP_ERR_INVALID, "block-banded LU: the band does not fit the LDS ring of the substitution kernel");
   HIP_TRY(s->lu_band.alloc((size_t)n * (2 * b + 1) * NF * NF, false));
   HIP_TRY(s->lu_dinv.alloc((size_t)n * NF * NF)); HIP_TRY(s->lu_y.alloc((size_t)n * NF));
   HIP_TRY(s->lu_pos.upload(t.lu_pos)); HIP_TRY(s->lu_node.upload(t.lu_node));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_band_solve<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring));
+  HIP_TRY(s->lu_part.alloc((size_t)kBandPanel * kBandChunks * NF));
   s->lu = BandLU{s->lu_band.p, s->lu_dinv.p, s->lu_pos.p, s->lu_node.p, n, b};
   s->lu_ready = true;
   return GMPNP_OK;
@@ -764,7 +762,20 @@ int band_factor(gmpnp_solver* s) {
 
 template <int NF>
 int band_substitute(gmpnp_solver* s, const double* rhs, double* x) {
-  hipLaunchKernelGGL((k_band_solve<NF>), dim3(1), dim3(NF * kWave), (size_t)(s->lu.b + 1) * NF * sizeof(double), s->stream, s->lu, rhs, x, s->lu_y.p);
+  const BandLU& lu = s->lu;
+  const int n = lu.n, P = kBandPanel;
+  double* y = s->lu_y.p; double* part = s->lu_part.p;
+  hipLaunchKernelGGL((k_band_gather<NF>), dim3((n * NF + 255) / 256), dim3(256), 0, s->stream, lu, rhs, y);
+  for (int K0 = 0; K0 < n; K0 += P) {   // forward: panels in elimination order
+    const int K1 = std::min(K0 + P, n);
+    hipLaunchKernelGGL((k_band_panel<NF, true>), dim3(K1 - K0, kBandChunks), dim3(NF * kWave), 0, s->stream, lu, (const double*)y, part, K0, K1);
+    hipLaunchKernelGGL((k_band_tri<NF, true>), dim3(1), dim3(NF * kWave), 0, s->stream, lu, y, (const double*)part, x, K0, K1);
+  }
+  for (int K0 = ((n - 1) / P) * P; K0 >= 0; K0 -= P) {   // backward: the same panels in reverse
+    const int K1 = std::min(K0 + P, n);
+    hipLaunchKernelGGL((k_band_panel<NF, false>), dim3(K1 - K0, kBandChunks), dim3(NF * kWave), 0, s->stream, lu, (const double*)y, part, K0, K1);
+    hipLaunchKernelGGL((k_band_tri<NF, false>), dim3(1), dim3(NF * kWave), 0, s->stream, lu, y, (const double*)part, x, K0, K1);
+  }
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;
 }

@@ -12,7 +12,7 @@
 //   k_band_step     pivot k: A_pq -= A_pk (D_k^-1 A_kq) for the (<= b)^2 window behind it, then D_{k+1}^-1.  Row k and
 //                   column k are only READ (they are the factors: L_pk = A_pk, U_kq = D_k^-1 A_kq with unit diagonal),
 //                   everything written lies strictly behind them: no hazard inside a launch, one launch per pivot.
-//   k_band_solve    forward and backward substitution, one workgroup walking the band rows (row dot products)
+//   k_band_panel / k_band_tri   forward and backward substitution in panels of 16 block rows (see below)
 //
 // Pivoting is partial INSIDE the NF x NF pivot block only; the caller checks the answer with the true residual
 // b - J x and refines (gmpnp_api.hip: band_solve).
@@ -155,110 +155,129 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
   }
 }
 
-// One lane's share of a band row (entries (qo, j) of the qo-th block behind `row`, row stride already applied), in
-// batches of kBandDotBatch entries per lane: all loads of a batch go out on clamped indices before the first use, the
-// masks come afterwards (a plain loop waits for every load before it issues the next: one memory latency per 64
-// entries; 54 -> 27 ms per substitution on the pore meshes).  Requesting the first batch of the NEXT row one step
-// ahead was tried and lost: two batches of doubles in flight per lane spill at 9 waves per workgroup.
-constexpr int kBandDotBatch = 16;
+// ---- substitution: panels of kBandPanel block rows, two launches per panel -----------------------------------------
+// x = U^-1 L^-1 rhs with y_k = D_k^-1 (rhs_k - sum_{q<k} A_kq y_q) and x_k = y_k - D_k^-1 sum_{q>k} A_kq x_q.  The chain
+// over the n block rows is what one workgroup used to walk alone (118 KB of band row per step through one CU: 27 ms on
+// L_50_R_5).  Now the band row of a block row is split at the panel boundary:
+//   k_band_panel   everything OUTSIDE the panel (blocks solved by earlier panels): one workgroup per (block row, chunk of
+//                  the band row), NF waves = the NF rows of the block, partial sums to `part` (summed in fixed order by the
+//                  next kernel: bitwise repeatable, no atomics);
+//   k_band_tri     the kBandPanel x kBandPanel block triangle INSIDE the panel: one workgroup, the whole triangle
+//                  requested into registers before the chain starts, D_k^-1 and the panel's vectors in LDS; a step is
+//                  products -> wave sums -> barrier -> D_k^-1 (NF threads) -> barrier.
+// y holds rhs in elimination order on entry of the forward sweep, y after it and x (elimination order) after the backward
+// sweep, which also scatters x to internal node order.
+constexpr int kBandPanel = 16;
+constexpr int kBandChunks = 4;      // chunks of the outside part of a band row (one workgroup each)
+constexpr int kBandDotBatch = 16;   // band-row entries per lane requested together (clamped indices, masks afterwards)
+
 template <int NF>
-__device__ __forceinline__ void band_row_load(const double* __restrict__ row, int count, int base, int lane, double (&v)[kBandDotBatch]) {
-  constexpr int BB = NF * NF;
-  const int last = max(count - 1, 0);
-#pragma unroll
-  for (int u = 0; u < kBandDotBatch; ++u) {
-    const int idx = min(base + u * kWave + lane, last), qo = idx / NF, jj = idx - qo * NF;
-    v[u] = row[(size_t)qo * BB + jj];
-  }
-}
-template <int NF>
-__device__ __forceinline__ double band_row_mac(const double (&v)[kBandDotBatch], const double* ring, int count, int base, int rb, int R, int lane) {
-  const int last = max(count - 1, 0);
-  double acc = 0.0;
-#pragma unroll
-  for (int u = 0; u < kBandDotBatch; ++u) {
-    const int raw = base + u * kWave + lane, idx = min(raw, last), qo = idx / NF, jj = idx - qo * NF;
-    int rr = rb + qo; rr -= (rr >= R) ? R : 0;
-    acc += (raw < count) ? v[u] * ring[rr * NF + jj] : 0.0;
-  }
-  return acc;
+__global__ __launch_bounds__(256) void k_band_gather(const BandLU lu, const double* __restrict__ rhs, double* __restrict__ y) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= lu.n * NF) return;
+  const int k = idx / NF;
+  y[idx] = rhs[(size_t)lu.lu_node[k] * NF + (idx - k * NF)];
 }
 
-// x = U^-1 L^-1 rhs.  ONE workgroup of NF waves; wave i owns row i of the current block row and reduces its band
-// dot product, then NF threads apply D_k^-1.  The last b solution blocks live in an LDS ring ((b+1) * NF doubles,
-// dynamic shared memory).  rhs and x are in internal node order, y is a work vector in elimination order.
-// Every step is a chain band row -> dot -> D_k^-1 -> ring; whatever does not depend on the previous block (the band
-// row, D_k^-1, the right-hand side) is requested ahead of the chain.
-template <int NF>
-__global__ __launch_bounds__(NF * kWave) void k_band_solve(const BandLU lu, const double* __restrict__ rhs, double* __restrict__ x,
-                                                            double* __restrict__ y) {
-  constexpr int U = kBandDotBatch;
-  extern __shared__ double ring[];   // [(b+1)][NF]
+// grid (K1 - K0, kBandChunks).  FWD: blocks [max(0, k-b), K0) of block row k; backward: blocks [K1, min(k+b, n-1)].
+template <int NF, bool FWD>
+__global__ __launch_bounds__(NF * kWave) void k_band_panel(const BandLU lu, const double* __restrict__ y, double* __restrict__ part,
+                                                            const int K0, const int K1) {
+  constexpr int U = kBandDotBatch, BB = NF * NF;
+  const int t = threadIdx.x, wv = t / kWave, lane = t - wv * kWave;
+  const int kk = blockIdx.x, ch = blockIdx.y, k = K0 + kk;
+  const int q_lo = FWD ? max(0, k - lu.b) : K1, q_hi = FWD ? K0 : min(k + lu.b, lu.n - 1) + 1;
+  const int nblk = max(q_hi - q_lo, 0), per = (nblk + kBandChunks - 1) / kBandChunks;
+  const int c_lo = q_lo + ch * per, c_hi = min(c_lo + per, q_hi);
+  const int count = max(c_hi - c_lo, 0) * NF, last = max(count - 1, 0);
+  double acc = 0.0;
+  if (count > 0) {   // uniform per workgroup
+    const double* row = band_at<NF>(lu, k, c_lo) + wv * NF;   // row wv of the blocks: NF entries every BB
+    const double* yv = y + (size_t)c_lo * NF;                 // entry (qo, j) of the row meets y[(c_lo + qo) * NF + j]
+    for (int base = 0; base < count; base += U * kWave) {
+      double w[U], z[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = min(base + u * kWave + lane, last), qo = idx / NF, jj = idx - qo * NF;
+        w[u] = row[(size_t)qo * BB + jj]; z[u] = yv[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += (base + u * kWave + lane < count) ? w[u] * z[u] : 0.0;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == kWave - 1) part[((size_t)kk * kBandChunks + ch) * NF + wv] = acc;
+}
+
+// one workgroup; np = K1 - K0 <= kBandPanel block rows.  Step s solves block row K0 + s (forward) / K1 - 1 - s (backward):
+// s blocks of the panel stand in its band row either way.
+template <int NF, bool FWD>
+__global__ __launch_bounds__(NF * kWave) void k_band_tri(const BandLU lu, double* __restrict__ y, const double* __restrict__ part,
+                                                          double* __restrict__ x, const int K0, const int K1) {
+  constexpr int P = kBandPanel, BB = NF * NF, UM = ((P - 1) * NF + kWave - 1) / kWave;
+  __shared__ double yp[P * NF];   // the panel's solution blocks
+  __shared__ double dl[P * BB];   // D_k^-1
+  __shared__ double rh[P * NF];   // forward: rhs_k - outside sum; backward: outside sum
+  __shared__ double yk[P * NF];   // backward: y_k
   __shared__ double st[NF];
   const int t = threadIdx.x, wv = t / kWave, lane = t - wv * kWave;
-  const int n = lu.n, b = lu.b, R = b + 1;
-  for (int idx = t; idx < n * NF; idx += NF * kWave) {   // right-hand side in elimination order
-    const int k = idx / NF;
-    y[idx] = rhs[(size_t)lu.lu_node[k] * NF + (idx - k * NF)];
+  const int np = K1 - K0;
+  // every global operand first: the triangle (registers), then D^-1, the outside sums and the panel's y
+  double v[P][UM];
+#pragma unroll
+  for (int s = 1; s < P; ++s) {
+    const int sc = min(s, np - 1), k = FWD ? K0 + sc : K1 - 1 - sc;
+    const double* row = (FWD ? band_at<NF>(lu, k, K0) : band_at<NF>(lu, k, k + 1)) + wv * NF;
+    const int last = max(sc * NF - 1, 0);
+#pragma unroll
+    for (int u = 0; u < UM; ++u)
+      if (u * kWave < s * NF) {   // compile time
+        const int idx = min(u * kWave + lane, last), qo = idx / NF, jj = idx - qo * NF;
+        v[s][u] = (np > 1) ? row[(size_t)qo * BB + jj] : 0.0;
+      }
+  }
+  for (int idx = t; idx < np * BB; idx += NF * kWave) dl[idx] = lu.dinv[(size_t)K0 * BB + idx];
+  if (t < np * NF) {
+    const int kk = t / NF;
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < kBandChunks; ++c) sacc += part[((size_t)kk * kBandChunks + c) * NF + (t - kk * NF)];
+    const double yv = y[(size_t)K0 * NF + t];
+    rh[t] = FWD ? yv - sacc : sacc;
+    if (!FWD) yk[t] = yv;
   }
   __syncthreads();
-  const int tc = t < NF ? t : 0;
-  // forward: y_k = D_k^-1 (rhs_k - sum_{q<k} A_kq y_q)
-  for (int k = 0; k < n; ++k) {
-    const int nb = min(b, k), qa = k - nb, count = nb * NF;
-    const double* row = band_at<NF>(lu, k, qa) + wv * NF;
-    const double* dptr = lu.dinv + ((size_t)k * NF + tc) * NF;
-    double d[NF];
 #pragma unroll
-    for (int m = 0; m < NF; ++m) d[m] = dptr[m];
-    const double bk = y[(size_t)k * NF + wv];
-    const int rb = qa % R;
-    double acc = 0.0;
-    for (int base = 0; base < count; base += U * kWave) {
-      double w[U];
-      band_row_load<NF>(row, count, base, lane, w);
-      acc += band_row_mac<NF>(w, ring, count, base, rb, R, lane);
-    }
-    acc = wave_sum(acc);
-    if (lane == kWave - 1) st[wv] = bk - acc;
-    __syncthreads();
-    if (t < NF) {
-      double r = 0.0;
+  for (int s = 0; s < P; ++s) {
+    if (s < np) {   // uniform
+      const int kk = FWD ? s : np - 1 - s;
+      const double* ys = yp + (FWD ? 0 : (kk + 1) * NF);   // entry (qo, j) of the in-panel row meets ys[qo * NF + j]
+      double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < NF; ++m) r += d[m] * st[m];
-      ring[(k % R) * NF + t] = r;
-      y[(size_t)k * NF + t] = r;
+      for (int u = 0; u < UM; ++u)
+        if (u * kWave < s * NF) {   // compile time
+          const int raw = u * kWave + lane;
+          acc += (raw < s * NF) ? v[s][u] * ys[min(raw, s * NF - 1)] : 0.0;
+        }
+      if (s > 0) acc = wave_sum(acc);
+      if (lane == kWave - 1) st[wv] = FWD ? rh[kk * NF + wv] - acc : rh[kk * NF + wv] + acc;
+      __syncthreads();
+      if (t < NF) {
+        double r = 0.0;
+#pragma unroll
+        for (int m = 0; m < NF; ++m) r += dl[kk * BB + t * NF + m] * st[m];
+        if (!FWD) r = yk[kk * NF + t] - r;
+        yp[kk * NF + t] = r;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  // backward: x_k = y_k - D_k^-1 sum_{q>k} A_kq x_q
-  for (int k = n - 1; k >= 0; --k) {
-    const int nb = min(b, n - 1 - k), count = nb * NF;
-    const double* row = band_at<NF>(lu, k, k + 1) + wv * NF;
-    const double* dptr = lu.dinv + ((size_t)k * NF + tc) * NF;
-    double d[NF];
-#pragma unroll
-    for (int m = 0; m < NF; ++m) d[m] = dptr[m];
-    const double yk = y[(size_t)k * NF + tc];
-    const int node = lu.lu_node[k];
-    const int rb = (k + 1) % R;
-    double acc = 0.0;
-    for (int base = 0; base < count; base += U * kWave) {
-      double w[U];
-      band_row_load<NF>(row, count, base, lane, w);
-      acc += band_row_mac<NF>(w, ring, count, base, rb, R, lane);
-    }
-    acc = wave_sum(acc);
-    if (lane == kWave - 1) st[wv] = acc;
-    __syncthreads();
-    if (t < NF) {
-      double r = yk;
-#pragma unroll
-      for (int m = 0; m < NF; ++m) r -= d[m] * st[m];
-      ring[(k % R) * NF + t] = r;
-      x[(size_t)node * NF + t] = r;
-    }
-    __syncthreads();
+  // results leave in one piece (a global store inside the chain would be drained at every barrier)
+  if (t < np * NF) {
+    const int kk = t / NF;
+    const double r = yp[t];
+    y[(size_t)K0 * NF + t] = r;
+    if (!FWD) x[(size_t)lu.lu_node[K0 + kk] * NF + (t - kk * NF)] = r;
   }
 }
 
