@@ -753,7 +753,7 @@ int band_factor(gmpnp_solver* s) {
   hipLaunchKernelGGL((k_band_step<NF>), dim3(1, 1), dim3(kBandThreads), 0, s->stream, lu, -1, s->status.p);
   for (int k = 0; k + 1 < lu.n; ++k) {
     const int w = std::min(lu.b, lu.n - 1 - k);
-    hipLaunchKernelGGL((k_band_step<NF>), dim3(grid_for(w, kBandColChunk), grid_for(w, G)), dim3(kBandThreads), 0, s->stream, lu, k, s->status.p);
+    hipLaunchKernelGGL((k_band_step<NF>), dim3(grid_for(w, kBandColChunk), grid_for(w, G) + 1), dim3(kBandThreads), 0, s->stream, lu, k, s->status.p);
   }
   HIP_TRY(hipGetLastError());
   s->direct_solves++;

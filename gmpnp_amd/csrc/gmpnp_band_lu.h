@@ -9,7 +9,7 @@
 // block band (BandLU in gmpnp_internal.h).  No MFMA: the update is a rank-NF (9) product per pivot, HBM-bound.
 //
 //   k_band_scatter  SELL values -> band storage
-//   k_band_step     pivot k: A_pq -= A_pk (D_k^-1 A_kq) for the (<= b)^2 window behind it, then D_{k+1}^-1.  Row k and
+//   k_band_step     pivot k: A_pq -= A_pk (D_k^-1 A_kq) for the (<= b)^2 window behind it; one extra workgroup: D_{k+1}^-1.  Row k and
 //                   column k are only READ (they are the factors: L_pk = A_pk, U_kq = D_k^-1 A_kq with unit diagonal),
 //                   everything written lies strictly behind them: no hazard inside a launch, one launch per pivot.
 //   k_band_panel / k_band_tri   forward and backward substitution in panels of 16 block rows (see below)
@@ -75,69 +75,46 @@ __device__ inline bool group16_inverse(double (&row)[2 * NF], int r) {
   return bad;
 }
 
-// grid (ceil(w / kBandColChunk), ceil(w / G)), w = min(b, n-1-k) ; k = -1: grid (1,1), only D_0^-1.
+// grid (ceil(w / kBandColChunk), ceil(w / G) + 1), w = min(b, n-1-k); k = -1: grid (1, 1).  The LAST grid row is one extra
+// workgroup (blockIdx.x = 0; the others of that row leave at once) that owns block (k+1, k+1): it applies pivot k to that one
+// block, stores it and inverts it — the NEXT launch's pivot — while the window is being updated by everybody else.  Done at
+// the end of the launch by the workgroup that holds the block, the dependent inverse (4 us of 16-lane shuffles) was a tail
+// every launch waited for.  k = -1: only D_0^-1.
 template <int NF>
 __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, const int k, int32_t* status) {
   constexpr int BB = NF * NF, G = kBandThreads / BB, QC = kBandColChunk;
   __shared__ double sU[QC * BB];
   __shared__ double sD[BB];
   const int t = threadIdx.x, g = t / BB, e = t - g * BB, i = e / NF, j = e - i * NF;
-  const bool first_wg = (blockIdx.x == 0 && blockIdx.y == 0);
-  double next_piv = 0.0;   // entry e of block (k+1, k+1) after this pivot's update (group 0 of the first workgroup)
-  if (k >= 0) {
-    const int w = min(lu.b, lu.n - 1 - k);
-    const int q0 = k + 1 + blockIdx.x * QC, p = k + 1 + blockIdx.y * G + g;
-    const int nq = min(QC, k + w + 1 - q0);
-    // every global operand is requested before the first barrier (clamped indices, masks afterwards): one memory
-    // latency per launch instead of three dependent ones; the launches of a factorisation run back to back
-    constexpr int UP = (QC * BB + kBandThreads - 1) / kBandThreads;   // U' entries per thread
-    const bool act = g < G && p <= k + w;
-    const int pc = min(p, k + w);
-    const double dk = lu.dinv[(size_t)k * BB + min(t, BB - 1)];
-    const double* Ak = band_at<NF>(lu, k, q0);
-    double a[UP][NF];
+  if (blockIdx.y == gridDim.y - 1) {   // the pivot workgroup
+    if (blockIdx.x != 0) return;
+    double entry = 0.0;
+    if (k >= 0) {
+      const int tc = min(t, BB - 1), ic = tc / NF, jc = tc - ic * NF;
+      double a9[NF], l9[NF];
+      const double* Ak = band_at<NF>(lu, k, k + 1);
+      const double* Lp = band_at<NF>(lu, k + 1, k) + ic * NF;
 #pragma unroll
-    for (int u = 0; u < UP; ++u) {
-      const int idx = min(t + u * kBandThreads, nq * BB - 1), qq = idx / BB, ee = idx - qq * BB, jj = ee % NF;
+      for (int m = 0; m < NF; ++m) { a9[m] = Ak[m * NF + jc]; l9[m] = Lp[m]; }
+      double* Cd = band_at<NF>(lu, k + 1, k + 1) + tc;
+      double acc = *Cd;
+      if (t < BB) sD[t] = lu.dinv[(size_t)k * BB + t];
+      __syncthreads();
+      double u = 0.0;   // same operation order as the window update below
 #pragma unroll
-      for (int l = 0; l < NF; ++l) a[u][l] = Ak[(size_t)qq * BB + l * NF + jj];
+      for (int ll = 0; ll < NF; ++ll) u += sD[ic * NF + ll] * a9[ll];
+      if (t < BB) sU[t] = u;
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < NF; ++m) acc -= l9[m] * sU[m * NF + jc];
+      if (t < BB) *Cd = acc;
+      entry = acc;
+    } else if (t < BB) {
+      entry = band_at<NF>(lu, 0, 0)[t];
     }
-    const double* Lp = band_at<NF>(lu, pc, k) + i * NF;
-    double l[NF];
-#pragma unroll
-    for (int m = 0; m < NF; ++m) l[m] = Lp[m];
-    double* C = band_at<NF>(lu, pc, q0) + e;
-    double cv[QC];
-#pragma unroll
-    for (int qq = 0; qq < QC; ++qq) cv[qq] = C[(size_t)min(qq, nq - 1) * BB];
-    if (t < BB) sD[t] = dk;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < UP; ++u) {
-      const int idx = t + u * kBandThreads;
-      const int ic = min(idx, nq * BB - 1), qq = ic / BB, ee = ic - qq * BB, m = ee / NF;
-      double acc = 0.0;
-#pragma unroll
-      for (int ll = 0; ll < NF; ++ll) acc += sD[m * NF + ll] * a[u][ll];
-      if (idx < nq * BB) sU[idx] = acc;
-    }
-    __syncthreads();
-    if (act) {
-#pragma unroll
-      for (int qq = 0; qq < QC; ++qq) {
-        double acc = cv[qq];
-#pragma unroll
-        for (int m = 0; m < NF; ++m) acc -= l[m] * sU[min(qq, nq - 1) * BB + m * NF + j];
-        if (qq < nq) C[(size_t)qq * BB] = acc;
-        if (qq == 0) next_piv = acc;
-      }
-    }
-  } else if (t < BB) {
-    next_piv = band_at<NF>(lu, 0, 0)[t];
-  }
-  if (first_wg && k + 1 < lu.n) {   // uniform per workgroup
-    __syncthreads();
-    if (t < BB) sD[t] = next_piv;
+    if (k + 1 >= lu.n) return;
+    // D_{k+1}^-1 (sD is free: its last readers passed the barrier above)
+    if (t < BB) sD[t] = entry;
     __syncthreads();
     if (t < kWave) {   // wave 0: its four 16-lane groups all do the same work, group 0 writes
       const int r = t & 15;
@@ -151,6 +128,54 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
         for (int jj = 0; jj < NF; ++jj) o[jj] = row[NF + jj];
       }
       if (t == 0 && bad) atomicOr(status, 2);
+    }
+    return;
+  }
+  const int w = min(lu.b, lu.n - 1 - k);
+  const int q0 = k + 1 + blockIdx.x * QC, p = k + 1 + blockIdx.y * G + g;
+  const int nq = min(QC, k + w + 1 - q0);
+  // every global operand is requested before the first barrier (clamped indices, masks afterwards): one memory
+  // latency per launch instead of three dependent ones; the launches of a factorisation run back to back
+  constexpr int UP = (QC * BB + kBandThreads - 1) / kBandThreads;   // U' entries per thread
+  const bool act = g < G && p <= k + w;
+  const int pc = min(p, k + w);
+  const double dk = lu.dinv[(size_t)k * BB + min(t, BB - 1)];
+  const double* Ak = band_at<NF>(lu, k, q0);
+  double a[UP][NF];
+#pragma unroll
+  for (int u = 0; u < UP; ++u) {
+    const int idx = min(t + u * kBandThreads, nq * BB - 1), qq = idx / BB, ee = idx - qq * BB, jj = ee % NF;
+#pragma unroll
+    for (int l = 0; l < NF; ++l) a[u][l] = Ak[(size_t)qq * BB + l * NF + jj];
+  }
+  const double* Lp = band_at<NF>(lu, pc, k) + i * NF;
+  double l[NF];
+#pragma unroll
+  for (int m = 0; m < NF; ++m) l[m] = Lp[m];
+  double* C = band_at<NF>(lu, pc, q0) + e;
+  double cv[QC];
+#pragma unroll
+  for (int qq = 0; qq < QC; ++qq) cv[qq] = C[(size_t)min(qq, nq - 1) * BB];
+  if (t < BB) sD[t] = dk;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < UP; ++u) {
+    const int idx = t + u * kBandThreads;
+    const int ic = min(idx, nq * BB - 1), qq = ic / BB, ee = ic - qq * BB, m = ee / NF;
+    double acc = 0.0;
+#pragma unroll
+    for (int ll = 0; ll < NF; ++ll) acc += sD[m * NF + ll] * a[u][ll];
+    if (idx < nq * BB) sU[idx] = acc;
+  }
+  __syncthreads();
+  if (act) {
+    const bool pivot_block = (p == k + 1 && q0 == k + 1);   // (k+1, k+1) belongs to the pivot workgroup
+#pragma unroll
+    for (int qq = 0; qq < QC; ++qq) {
+      double acc = cv[qq];
+#pragma unroll
+      for (int m = 0; m < NF; ++m) acc -= l[m] * sU[min(qq, nq - 1) * BB + m * NF + j];
+      if (qq < nq && !(pivot_block && qq == 0)) C[(size_t)qq * BB] = acc;
     }
   }
 }
