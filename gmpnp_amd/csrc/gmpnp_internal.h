@@ -30,7 +30,7 @@ constexpr int kTileAggs = 6;         // coarse aggregates the rows of one tile m
 constexpr int kTileCols = 224;       // distinct column nodes a tile may reference (x staged in LDS: kTileCols*NF doubles)
 constexpr int kSlicePad = 16;       // per-(slice,kpos) column-index record length (>= rows per slice: 7 or 9)
 #ifndef GMPNP_ROW_PRELOAD_B
-#define GMPNP_ROW_PRELOAD_B 2  // B half of the two-launch form: its register budget allows a second block position up front
+#define GMPNP_ROW_PRELOAD_B 1  // B half of the two-launch form: a second block position up front fits its registers and was the default until the hand-over got short — now it arrives late like in A (same box: B 9.68 -> 9.46 us, 664/674 -> 671/678 its/s with one position)
 #endif
 #ifndef GMPNP_CLAMP_PRELOAD
 #define GMPNP_CLAMP_PRELOAD 1  // preload positions past a slice's end repeat its last position instead of reading the next slice
