@@ -207,6 +207,29 @@ def test_band_lu_matches_sparse_lu(pore10, gpu_lib):
         assert not xz.any()
 
 
+@pytest.mark.parametrize("rings,layers", [(1, 1), (1, 4), (2, 5)])
+def test_band_lu_on_meshes_smaller_than_a_substitution_panel(rings, layers, gpu_lib):
+    """Generated cylinders of 14 / 35 / 114 vertices: fewer block rows than one 16-row panel of the substitution, a band narrower
+    than a panel (the library widens the stored band to 15 blocks), a last panel of 3 rows — against SciPy's sparse LU."""
+    import closed_forms as cf
+    prob = cf._base(10e-9, 5e-9, 0, reactions=True, wall_flux=True, steady=False, q_scale=1.0, coarse=(rings, layers))[0]
+    nv = prob.coords.shape[0]
+    assert nv == (1 + 3 * rings * (rings + 1)) * (layers + 1)
+    u, un = random_state(nv, prob.nf - 1, seed=11)
+    Fo, Ao = O.assemble(prob, u, un)
+    lu = spla.splu(Ao.tocsc())
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u, un)
+        dev.assemble(True)
+        for rhs in (Fo, np.random.default_rng(3).standard_normal(prob.ndof)):
+            x, st = dev.linear_solve(rhs, gpu_lib.LINEAR_BAND_LU)
+            # the library stops at 1e-10 against ITS matrix; ||x|| ~ 1e4 ||b|| on these random states, so the oracle's matrix
+            # (equal to 1e-13) sees a residual of up to 1e-9
+            assert st["converged"] and relerr(Ao @ x, rhs) < 5e-9 and relerr(x, lu.solve(rhs)) < 1e-6
+            x2, _ = dev.linear_solve(rhs, gpu_lib.LINEAR_BAND_LU)
+            assert np.array_equal(x, x2)
+
+
 def test_band_lu_is_3d_only(edl1, gpu_lib):
     prob = edl1[2]
     with gpu_lib.DeviceSolver(prob) as dev:
