@@ -75,7 +75,7 @@ __device__ inline bool group16_inverse(double (&row)[2 * NF], int r) {
   return bad;
 }
 
-// grid (ceil(w / kBandColChunk), ceil(w / G) + 1), w = min(b, n-1-k); k = -1: grid (1, 1).  The LAST grid row is one extra
+// grid (ceil(w / kBandColChunk), 1 + ceil(w / G)), w = min(b, n-1-k); k = -1: grid (1, 1).  The FIRST grid row is one extra
 // workgroup (blockIdx.x = 0; the others of that row leave at once) that owns block (k+1, k+1): it applies pivot k to that one
 // block, stores it and inverts it — the NEXT launch's pivot — while the window is being updated by everybody else.  Done at
 // the end of the launch by the workgroup that holds the block, the dependent inverse (4 us of 16-lane shuffles) was a tail
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
   __shared__ double sU[QC * BB];
   __shared__ double sD[BB];
   const int t = threadIdx.x, g = t / BB, e = t - g * BB, i = e / NF, j = e - i * NF;
-  if (blockIdx.y == gridDim.y - 1) {   // the pivot workgroup
+  if (blockIdx.y == 0) {   // the pivot workgroup: FIRST grid row, so that it is dispatched with the first workgroups whatever the window size
     if (blockIdx.x != 0) return;
     double entry = 0.0;
     if (k >= 0) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBandThreads) void k_band_step(const BandLU lu, con
     return;
   }
   const int w = min(lu.b, lu.n - 1 - k);
-  const int q0 = k + 1 + blockIdx.x * QC, p = k + 1 + blockIdx.y * G + g;
+  const int q0 = k + 1 + blockIdx.x * QC, p = k + 1 + ((int)blockIdx.y - 1) * G + g;
   const int nq = min(QC, k + w + 1 - q0);
   // every global operand is requested before the first barrier (clamped indices, masks afterwards): one memory
   // latency per launch instead of three dependent ones; the launches of a factorisation run back to back
