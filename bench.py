@@ -25,9 +25,11 @@ Extra objects on the JSON line:
   roofline      dominant kernels = the two fused BiCGStab half-iterations (k_half_a / k_half_b on meshes whose workgroups are
                 all resident at once, else k_bicg_a / k_bicg_b after a separate coarse launch): one SELL block SpMV each
                 plus the vector updates.  achieved = algorithmic bytes of ONE SpMV (648 nb + 4 nb + 4 (nv+1) +
-                16 nd; the vector traffic fused in is not counted) / mean kernel duration, sampled LIVE during the timed
-                region: every 32nd launch carries a start/stop HIP event pair attached to the dispatch itself
-                (hipExtLaunchKernelGGL on the solver's stream), i.e. the kernel's own begin-to-end time.
+                16 nd; the vector traffic fused in is not counted) / mean duration of a half-iteration, measured LIVE
+                during the timed region: the first burst of every 4th linear solve — 40-odd back-to-back half-iterations,
+                all of them live — sits between ONE pair of HIP events on the solver's stream; elapsed time / number of
+                half-iterations = the launch plus the gap to the next one (in the forms with a separate coarse launch, that
+                launch too).  rocprofv3's kernel durations of the same command (profiles/) are the check.
   cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU) timed on rank 0 / N = 1 over the first 3 Newton iterations
                 of the same window, on 1 thread and on all cores (about 35 s together); kind = "port" (FEniCS itself
                 cannot be installed).  `full_window_recorded` = the committed timing of the whole 50-step window.
@@ -143,7 +145,7 @@ def main():
     _, Lnm, _, Rnm = a.mesh.split("_")
     common = dict(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine)
     run = PoreRun(device_kwargs={"device_id": local, "shared_device": int(shared),
-                                 "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "32"))}, **common)
+                                 "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "4"))}, **common)
     nv = run.mesh.num_vertices
 
     def reset(r):
@@ -267,8 +269,8 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
         else:
             kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-        # what an EMPTY start/stop event pair measures on this stream: the sampled durations carry that much dispatch /
-        # completion latency on top of the kernel's own time (rocprofv3's kernel trace of the same command is the check)
+        # what an EMPTY start/stop event pair measures on this stream: each timed burst carries that much ONCE (a burst is 2 x
+        # ~20 launches), reported for information
         try:
             ev_overhead = dev.event_overhead(200)
         except Exception:  # noqa: BLE001
@@ -300,6 +302,7 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
                          "empty_event_pair_us": ev_overhead,   # information only: `achieved` uses the raw event time (conservative)
+                         "timing": "one HIP event pair around the first burst of every Nth solve (back-to-back live half-iterations); mean = elapsed / half-iterations, launch gaps included",
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
                          "launches_per_krylov_iteration": launches},
         }

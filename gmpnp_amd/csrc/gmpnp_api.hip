@@ -120,6 +120,8 @@ struct gmpnp_solver {
   int coarse_lag = 3;   // rebuild the coarse inverse alone every coarse_lag-th Newton iteration of a solve (measured best: 1 -> 3 costs 0.7 % more Krylov iterations and saves 155 us per skipped rebuild)
   // SpMV event sampling (eager mode)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
+  std::vector<int> ev_halves;   // half-iterations inside bracket i (0: the bracket is not counted)
+  int64_t solve_index = 0;
   int64_t spmv_launched = 0, spmv_sampled = 0; double spmv_us_sum = 0.0;
   // block-tridiagonal direct solver (1D): cyclic-reduction pyramid
   std::vector<TriLevel> tri; DevBuf<double> tri_store; DevBuf<int32_t> tri_kpos; bool tri_ok = false;
@@ -345,50 +347,32 @@ int setup_preconditioner(gmpnp_solver* s, int mode, bool refresh = true, bool re
   return GMPNP_OK;
 }
 
-// One launch of a fused half-iteration, optionally bracketed by events (eager mode sampling).
+// One half-iteration of the fused BiCGStab: one launch (coarse workgroups inside the tile launch), two, or three.
 template <int NF, int WHICH>
-int launch_half(gmpnp_solver* s, int k, bool sample) {
-  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (sample) {
-    if (s->ev_used == s->ev_pool.size()) {
-      hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); s->ev_pool.push_back({a, b});
-    }
-    ev = &s->ev_pool[s->ev_used++];
-  }
+int launch_half(gmpnp_solver* s, int k) {
   const dim3 cg(std::max(1, s->t.nagg));
-  // sampled launches attach the events to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the kernel's
-  // own begin-to-end time, the quantity rocprofv3's kernel trace reports
   if (s->fused_half) {
     const dim3 fg(s->t.nagg + s->t.own_ntiles);
     const unsigned target = (unsigned)(++s->fused_seq);
-    if (WHICH == 0) {
-      if (ev) hipExtLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
-      else hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
-    } else {
-      if (ev) hipExtLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k, target);
-      else hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
-    }
+    if (WHICH == 0) hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
+    else hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
   } else if (s->matp) {   // materialised vectors: coarse kernel, streaming vector update, tile kernel staging one vector
     const dim3 vg(grid_for(s->ndof, 256));
     if (WHICH == 0) {
       hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL(k_vec_a, vg, dim3(256), 0, s->stream, s->c, k);
-      if (ev) hipExtLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-      else hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
     } else {
       hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL(k_vec_b, vg, dim3(256), 0, s->stream, s->c, k);
-      if (ev) hipExtLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-      else hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
     }
   } else if (WHICH == 0) {
     hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
-    if (ev) hipExtLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-    else hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    hipLaunchKernelGGL((k_bicg_a<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
   } else {
     hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
-    if (ev) hipExtLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, ev->first, ev->second, 0, s->c, k);
-    else hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+    hipLaunchKernelGGL((k_bicg_b<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
   }
   if (s->prereduce) {   // the sums the next coarse kernel reads
     const int n = s->ncoarse;
@@ -401,9 +385,10 @@ int launch_half(gmpnp_solver* s, int k, bool sample) {
 
 int drain_spmv_events(gmpnp_solver* s) {
   for (size_t i = 0; i < s->ev_used; ++i) {
+    if (s->ev_halves[i] <= 0) continue;   // a bracket that reached into the launches behind the end of its solve
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second));
-    s->spmv_us_sum += 1000.0 * ms; s->spmv_sampled++;
+    s->spmv_us_sum += 1000.0 * ms; s->spmv_sampled += s->ev_halves[i];
   }
   s->ev_used = 0;
   return GMPNP_OK;
@@ -412,11 +397,10 @@ int drain_spmv_events(gmpnp_solver* s) {
 // Iteration k of the solve (k = 0, 1, ...): the index is a kernel ARGUMENT, so no kernel has to read it back from
 // memory before it can address its parity buffers.
 template <int NF>
-int enqueue_iteration(gmpnp_solver* s, int k, bool allow_sampling) {
-  const int every = s->opts.profile_every;
-  int rc = launch_half<NF, 0>(s, k, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
+int enqueue_iteration(gmpnp_solver* s, int k) {
+  int rc = launch_half<NF, 0>(s, k);
   if (rc) return rc;
-  return launch_half<NF, 1>(s, k, allow_sampling && every > 0 && (s->spmv_launched % every) == 0);
+  return launch_half<NF, 1>(s, k);
 }
 
 // Solve J dx = rhs (rhs already in c.kr on the device, ||rhs|| = bnorm) with the fused right-preconditioned BiCGStab;
@@ -458,13 +442,28 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
   first = ((first + B - 1) / B) * B;
   int next_k = 0;  // iteration index of the next launch (the device stops advancing once `done` is set)
   auto burst = [&](int iters) -> int {
-    for (int it = 0; it < iters; ++it) { int rc = enqueue_iteration<NF>(s, next_k++, true); if (rc) return rc; }
+    for (int it = 0; it < iters; ++it) { int rc = enqueue_iteration<NF>(s, next_k++); if (rc) return rc; }
     return GMPNP_OK;
   };
   KrylovScalars res = init;
   int launched = 0, slot = 0;
+  // Timing for the roofline (opts.profile_every = N > 0): ONE event pair around the first burst of every Nth solve — a run of
+  // back-to-back half-iterations, all of them live (checked against the solve's iteration count afterwards).  Elapsed time /
+  // half-iterations = what a half-iteration costs in the solve, launch gaps included.  (Events attached to single dispatches
+  // read 1.5 us more than rocprofv3's kernel durations: a dispatch with a completion signal of its own is a slower dispatch.)
+  const int every = s->opts.profile_every;
+  long bracket = -1;
+  if (every > 0 && !restart && !res.done && first >= 2 && (s->solve_index++ % every) == 0) {
+    if (s->ev_used == s->ev_pool.size()) {
+      hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); s->ev_pool.push_back({a, b}); s->ev_halves.push_back(0);
+    }
+    bracket = (long)s->ev_used++;
+    s->ev_halves[bracket] = 0;
+    HIP_TRY(hipEventRecord(s->ev_pool[bracket].first, s->stream));
+  }
   if (!res.done) {
     int rc = burst(first); if (rc) return rc;
+    if (bracket >= 0) HIP_TRY(hipEventRecord(s->ev_pool[bracket].second, s->stream));
     launched = first;
     bool mirror_ok = s->host_poll != 0;
     while (mirror_ok) {
@@ -501,6 +500,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
     // the sampled launches' events are read at the next point where the stream is synchronised anyway (residual(),
     // the end of gmpnp_linear_solve, gmpnp_spmv_profile): no wait of its own
   }
+  if (bracket >= 0 && res.done == 1 && res.iters > first) s->ev_halves[bracket] = 2 * first;   // every launch of the burst did its work
   if (!restart) s->last_krylov_iters[use_coarse] = res.iters;
   s->last_done = res.done;
   if (st) { st->iterations = res.iters; st->converged = (res.done == 1); st->residual_norm = std::sqrt(res.rr); st->rhs_norm = bnorm; }

@@ -149,7 +149,7 @@ typedef struct {
   int32_t krylov_batch;   /* iterations of the first burst of a BiCGStab solve; 0 = default (sized from the
                              previous solves; afterwards the host keeps one iteration queued ahead of the progress
                              the kernels report into pinned memory) */
-  int32_t profile_every;  /* time every Nth SpMV launch with HIP events; 0 = off */
+  int32_t profile_every;  /* N > 0: the first burst of every Nth Krylov solve runs between a pair of HIP events (gmpnp_spmv_profile); 0 = off */
   int32_t launch_form;    /* launches per BiCGStab iteration: 0 = automatic (2 when hipOccupancyMaxActiveBlocksPerMultiprocessor
                              proves every workgroup of a launch resident at once, else 4), 2, 4.  Asking for 2 on a
                              problem that is not resident is refused (GMPNP_ERR_INVALID). */
@@ -342,8 +342,9 @@ int gmpnp_group_assign_previous(gmpnp_group* g);
  * half-iterations (coarse workgroups inside the tile launch), 14/15 = the tile kernels of the materialised vector form,
  * 16/17 = its streaming vector updates. */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
-/* Fused BiCGStab half-iteration launches (k_bicg_a / k_bicg_b: SpMV + vector updates) sampled with HIP events since
- * the last call (opts.profile_every): count, mean microseconds between the two events of a bracket. */
+/* Fused BiCGStab half-iterations (SpMV + vector updates) timed with HIP events since the last call (opts.profile_every):
+ * n_sampled = half-iterations inside the timed bursts (each a run of back-to-back launches, all of them before the end of
+ * their solve), mean_us = elapsed time / n_sampled (launch gaps included), n_launched = all half-iterations launched. */
 int gmpnp_spmv_profile(gmpnp_solver* s, int64_t* n_sampled, double* mean_us, int64_t* n_launched);
 /* Mean elapsed time of an EMPTY event pair on the handle's stream (what a sampled launch's bracket adds). */
 int gmpnp_event_overhead(gmpnp_solver* s, int32_t pairs, double* mean_us);
