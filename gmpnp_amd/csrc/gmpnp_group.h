@@ -97,6 +97,13 @@ struct gmpnp_group {
   std::vector<hipStream_t> own_stream;  // in-process mode: the handles' own streams, given back at destroy
   std::vector<std::vector<int>> peer_slot;  // in-process mode: peer_slot[d][j] = index of d in the neighbour list of d's neighbour j
   int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
+  // Coarse operator of the two-level preconditioner: rebuilt (Galerkin product, one all-reduce, 72 x 72 inverse: 180 us in the
+  // stream) for the first Newton iteration of a solve and every third one after it; in between the solves run with the
+  // inverse they have — any coarse operator gives a valid right preconditioner (the single-GPU solver does the same with a
+  // side stream).  A solve that needs 25 % more iterations than the last one with a fresh inverse forces a rebuild
+  // (from the zero state the Jacobian of the second Newton iteration is far from the first one's: 160 instead of 73 iterations).
+  // Every figure here is identical on all ranks, so all ranks decide alike.
+  int coarse_age = 1 << 20, coarse_fresh_iters = 0; bool coarse_slow = false;
   // peer-mailbox transport (gmpnp_group_peer_begin / _connect): one k_peer_exchange launch per collective, no library, no host step
   bool peer = false, peer_connected = false;
   unsigned* peer_counter = nullptr;                        // arrival counter of k_dist_reduce_exchange (device)
@@ -257,7 +264,7 @@ int group_residual(gmpnp_group* g, double* norm, int* flags) {
 
 // ---- preconditioner of the partitioned operator: node-block Jacobi (ghost blocks from their owners) + GLOBAL slab coarse space ----
 template <int NF>
-int group_setup(gmpnp_group* g, int mode) {
+int group_setup(gmpnp_group* g, int mode, bool rebuild_coarse = true) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   for (gmpnp_solver* s : g->dom) {
     s->c.use_coarse = use_coarse;
@@ -267,7 +274,7 @@ int group_setup(gmpnp_group* g, int mode) {
   int rc = group_exchange(g, NF * NF, 1, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->Dinv.p; return w; }); if (rc) return rc;
   for (gmpnp_solver* s : g->dom)
     hipLaunchKernelGGL((k_scale_columns<NF>), dim3(grid_for(s->c.n_work * kWave, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
-  if (use_coarse) {
+  if (use_coarse && rebuild_coarse) {
     for (gmpnp_solver* s : g->dom) {
       const int n = s->ncoarse;
       hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
@@ -443,7 +450,11 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
   bool done = conv(r);
   while (!done && st.iterations < o.maximum_iterations) {
     for (gmpnp_solver* s : g->dom) { rc = launch_jac_gather<DIM, NF>(s); if (rc) return rc; s->jacobian_valid = true; }
-    rc = group_setup<NF>(g, o.linear_solver); if (rc) return rc;
+    const bool two_level = o.linear_solver == GMPNP_LINEAR_BICGSTAB_TWOLEVEL;
+    // (a solve that starts from a state set from outside — the zero state of time step 0 — rebuilds every time: its Jacobians differ
+    // too much, 203 instead of 56 iterations with the first iteration's inverse in the second)
+    const bool rebuild = two_level && (st.iterations == 0 || g->coarse_age >= 2 || g->coarse_slow || g->dom[0]->state_jumped);
+    rc = group_setup<NF>(g, o.linear_solver, rebuild); if (rc) return rc;
     gmpnp_linear_stats_t ls{};
     // Warm start, as in the single-GPU Newton (gmpnp_api.hip): with the damped update consecutive corrections satisfy
     // dx_{k+1} = (1 - w) dx_k + O(|dx_k|^2); x0 = (1-w) dx_k [+ (1-w)^2 (dx_k - (1-w) dx_{k-1})] is accepted when it removes at
@@ -511,6 +522,10 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
     if (st.iterations < GMPNP_MAX_NEWTON_HISTORY) st.krylov_per_iteration[st.iterations] = ls.iterations;
     st.krylov_iterations += ls.iterations;
     if (rc) return rc;
+    if (two_level) {
+      if (rebuild) { g->coarse_age = 0; g->coarse_fresh_iters = ls.iterations; g->coarse_slow = false; }
+      else { g->coarse_age++; g->coarse_slow = ls.iterations > g->coarse_fresh_iters + g->coarse_fresh_iters / 4 + 5; }
+    }
     rc = group_update<NF>(g, o.linear_solver, o.relaxation_parameter, warm); if (rc) return rc;
     st.iterations++;
     rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
