@@ -12,10 +12,11 @@ t = 0), then EXACTLY K steps from t = 0 are timed between barrier + synchronize 
 all ranks / max-over-ranks time.
 
 N > 1: `value` is the north-star quantity — ONE L_50_R_5 problem, mesh-partitioned over the N GPUs (z-slab partitions,
-one process per GPU; ghost-row exchange and one fused all-reduce per BiCGStab half-iteration inside libgmpnp.so — peer
-mailboxes over xGMI, else RCCL, else host-staged — global coarse space): strong scaling, Newton iterations of the one
-problem / max-over-ranks time.  On a
-3.7k-vertex mesh that cannot beat one GPU (a half-iteration is 13 us of kernel against two collectives); `--refine 1|2`
+one process per GPU; ghost-row exchange and one fused all-reduce per BiCGStab half-iteration inside libgmpnp.so, global
+coarse space): strong scaling, Newton iterations of the one problem / max-over-ranks time.  Both device transports are timed —
+peer mailboxes over xGMI and RCCL — and the faster one is `value` (`partitioned.transports_timed` lists both); the host-staged
+transport only runs when neither works.  On a
+3.7k-vertex mesh that cannot beat one GPU (a half-iteration is 10 us of kernel against two collectives); `--refine 1|2`
 gives the sizes where it can.  The same invocation first times N independent replicas of the problem, one per GPU (the
 parameter-sweep mapping of BASELINE configs[4], no collective, weak scaling) and reports them under `replicas`; should the
 partitioned phase fail or hang on the node (its RCCL path cannot be rehearsed on a one-GPU box), the replica figure is
@@ -204,24 +205,36 @@ def main():
     if (world > 1 or a.force_partitioned) and not a.replicas_only:
         import threading
 
+        state = {"best": None}
+
         def bail():
             # The RCCL path of the partitioned solve cannot be rehearsed on a one-GPU box (RCCL refuses two ranks on one
-            # device): if it hangs on the node, the replica measurement above is still reported, with the reason.
+            # device): if a transport hangs on the node, what was measured before it — another transport's rate, or the replica
+            # measurement above alone — is still reported, with the reason.
             if rank == 0:
-                emit({"error": "partitioned phase did not finish within %d s" % a.partition_timeout})
+                best = state["best"]
+                if best is not None:
+                    best = dict(best, note="a later transport did not finish within %d s" % a.partition_timeout)
+                emit(best or {"error": "partitioned phase did not finish within %d s" % a.partition_timeout})
             os._exit(0)
 
         wd = threading.Timer(a.partition_timeout, bail)
         wd.daemon = True
         wd.start()
-        # transports in order of preference: peer mailboxes (one kernel launch per collective: stores into the other ranks'
-        # IPC-mapped mailboxes, xGMI between GPUs); RCCL inside the library; the library's host-staged transport over
-        # torch.distributed/gloo (PCIe per collective): same algorithm in all three
-        errors = []
+        # Transports: peer mailboxes (one kernel launch per collective: stores into the other ranks' IPC-mapped mailboxes, xGMI
+        # between GPUs); RCCL inside the library; the library's host-staged transport over torch.distributed/gloo (PCIe per
+        # collective) — same algorithm in all three.  On a node BOTH device transports are timed and the faster one is the
+        # headline (which of them wins over xGMI could not be measured on a one-GPU box); the host-staged one only runs when
+        # neither works.
+        errors, tried = [], []
         order = ["peer"] + (["rccl"] if backend == "nccl" else []) + ["host"]
+        first_only = world == 1
         if os.environ.get("GMPNP_BENCH_TRANSPORTS"):   # rehearsal / comparison runs: e.g. "host" or "rccl,host"
             order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "rccl", "host")]
+            first_only = True
         for transport in order:
+            if state["best"] is not None and (first_only or transport == "host"):
+                break
             try:
                 prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport}, **common)
                 try:
@@ -233,18 +246,22 @@ def main():
                         raise RuntimeError("%d Newton iterations instead of the single-GPU run's %d" % (pits, sum(run.newton_its)))
                     tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    part = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
-                            "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport}
+                    res = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
+                           "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport}
+                    tried.append({"transport": transport, "value": res["value"], "krylov_iterations": pkry})
+                    if state["best"] is None or res["value"] > state["best"]["value"]:   # identical on every rank (all-reduced time)
+                        state["best"] = res
                 finally:
                     prun.sys.close()
-                break
             except Exception as e:  # noqa: BLE001
                 errors.append("%s transport: %s: %s" % (transport, type(e).__name__, str(e)[:300]))
                 # every rank must take the same branch: an error on one rank only would leave the others in a collective,
                 # where the watchdog ends the phase
-                part = {"error": "; ".join(errors)}
-        if part is not None and errors and "value" in part:
-            part["earlier_errors"] = errors
+        part = state["best"] if state["best"] is not None else {"error": "; ".join(errors) or "no transport"}
+        if "value" in part:
+            part = dict(part, transports_timed=tried)
+            if errors:
+                part["earlier_errors"] = errors
         wd.cancel()
 
     if rank == 0:
@@ -322,7 +339,7 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
                                                  % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
                 out["roofline"]["note"] = "kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)"
                 out["replicas"] = replicas
-                out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "earlier_errors") if k in part}
+                out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "transports_timed", "earlier_errors", "note") if k in part}
             else:
                 out["replicas"] = replicas
                 out["partitioned"] = part or {"error": "not run (--replicas-only)"}
