@@ -13,9 +13,9 @@ all ranks / max-over-ranks time.
 
 N > 1: `value` is the north-star quantity — ONE L_50_R_5 problem, mesh-partitioned over the N GPUs (z-slab partitions,
 one process per GPU; ghost-row exchange and one fused all-reduce per BiCGStab half-iteration inside libgmpnp.so, global
-coarse space): strong scaling, Newton iterations of the one problem / max-over-ranks time.  Both device transports are timed —
-peer mailboxes over xGMI and RCCL — and the faster one is `value` (`partitioned.transports_timed` lists both); the host-staged
-transport only runs when neither works.  On a
+coarse space): strong scaling, Newton iterations of the one problem / max-over-ranks time.  Transports in order of preference:
+peer mailboxes over xGMI, RCCL, host-staged; the first that works is `value` (GMPNP_BENCH_ALL_TRANSPORTS=1 times both device
+transports and takes the faster, `partitioned.transports_timed`).  On a
 3.7k-vertex mesh that cannot beat one GPU (a half-iteration is 10 us of kernel against two collectives); `--refine 1|2`
 gives the sizes where it can.  The same invocation first times N independent replicas of the problem, one per GPU (the
 parameter-sweep mapping of BASELINE configs[4], no collective, weak scaling) and reports them under `replicas`; should the
@@ -221,14 +221,14 @@ def main():
         wd = threading.Timer(a.partition_timeout, bail)
         wd.daemon = True
         wd.start()
-        # Transports: peer mailboxes (one kernel launch per collective: stores into the other ranks' IPC-mapped mailboxes, xGMI
-        # between GPUs); RCCL inside the library; the library's host-staged transport over torch.distributed/gloo (PCIe per
-        # collective) — same algorithm in all three.  On a node BOTH device transports are timed and the faster one is the
-        # headline (which of them wins over xGMI could not be measured on a one-GPU box); the host-staged one only runs when
-        # neither works.
+        # Transports in order of preference: peer mailboxes (one kernel launch per collective: stores into the other ranks'
+        # IPC-mapped mailboxes, xGMI between GPUs); RCCL inside the library; the library's host-staged transport over
+        # torch.distributed/gloo (PCIe per collective) — same algorithm in all three.  The first one that works is the headline;
+        # GMPNP_BENCH_ALL_TRANSPORTS=1 times BOTH device transports on a node and reports the faster one (not the default: a
+        # second communicator set-up in the same process is one more thing that can go wrong after a result is in hand).
         errors, tried = [], []
         order = ["peer"] + (["rccl"] if backend == "nccl" else []) + ["host"]
-        first_only = world == 1
+        first_only = os.environ.get("GMPNP_BENCH_ALL_TRANSPORTS", "0") in ("", "0")
         if os.environ.get("GMPNP_BENCH_TRANSPORTS"):   # rehearsal / comparison runs: e.g. "host" or "rccl,host"
             order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "rccl", "host")]
             first_only = True
