@@ -34,6 +34,15 @@ Extra objects on the JSON line:
   cpu_baseline  the CPU oracle (NumPy assembly + SciPy SuperLU) timed on rank 0 / N = 1 over the first 3 Newton iterations
                 of the same window, on 1 thread and on all cores (about 35 s together); kind = "port" (FEniCS itself
                 cannot be installed).  `full_window_recorded` = the committed timing of the whole 50-step window.
+                `banded_all_cores`: the same Jacobian in the library's slab order is a band of ~1,650 scalars; one LAPACK
+                dgbsv (scipy.linalg.solve_banded, threaded BLAS) on every core of the box, next to the serial SuperLU leg —
+                the stand-in for the reference's MUMPS (3D:792) that uses the box.
+  edl50         (N = 1) BASELINE configs[1]: the 1D script's 100 dry-run steps (50 um mesh, 7 fields, 41,937 dofs; reference
+                1D:256-268) — Newton iterations / s, the roofline of its direct solve (block cyclic reduction, k_bcr_*), and the
+                C oracle timed on the same 100 steps.  `--case edl50` makes that the headline line instead.
+
+Exit codes: 0 = a line was printed and every phase finished; 3 = the partitioned phase hung and the watchdog printed the line
+(with what was measured before) — the driver sees the hang.
 """
 import argparse
 import json
@@ -60,6 +69,9 @@ def parse():
                    help="also at N = 1: run the partitioned phase (one partition, RCCL communicator of one rank) — rehearsal of "
                         "the N > 1 code path on a one-GPU box; reported under `partitioned_rehearsal`, `value` stays the single-GPU solver's")
     p.add_argument("--partition-timeout", type=int, default=240, help="seconds the partitioned phase may take before the replica result is reported alone")
+    p.add_argument("--case", choices=["pore50", "edl50"], default="pore50",
+                   help="pore50 = BASELINE configs[2] (the headline); edl50 = BASELINE configs[1], the 1D script's 100 dry-run steps")
+    p.add_argument("--no-edl50", action="store_true", help="N = 1: skip the secondary 1D measurement")
     return p.parse_args()
 
 
@@ -91,6 +103,11 @@ def cpu_baseline(run, max_newton=3):
         legs[name] = {"threads": lim, "newton_iterations": st.iterations, "seconds": wall, "assembly_seconds": st.t_assemble,
                       "lu_seconds": st.t_linear, "value": st.iterations / wall}
     one = legs["one_thread"]
+    banded = None
+    try:
+        banded = banded_leg(O, prob, u0, un)
+    except Exception as e:  # noqa: BLE001   (a missing LAPACK binding must not cost the bench line)
+        banded = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     window = None
     wpath = os.path.join(ROOT, "profiles", "r02", "cpu_window_1thread.json")
     if os.path.exists(wpath):
@@ -100,8 +117,114 @@ def cpu_baseline(run, max_newton=3):
             "sample": "first %d Newton iterations of time step 0 of the same window (same mesh/parameters, zero initial guess): "
                       "NumPy P1 assembly of J and F %.1f s + SciPy SuperLU factor+solve %.1f s on 1 thread; FEniCS/MUMPS "
                       "itself is not installable on this box" % (one["newton_iterations"], one["assembly_seconds"], one["lu_seconds"]),
-            "all_cores": legs["all_cores"], "one_thread": one, "host_cpus": os.cpu_count(),
+            "all_cores": legs["all_cores"], "one_thread": one, "host_cpus": os.cpu_count(), "banded_all_cores": banded,
             "full_window_recorded": window}
+
+
+def banded_leg(O, prob, u0, un):
+    """One Newton iteration's linear algebra the way a band solver does it, on every core: the Jacobian of time step 0 in the
+    library's slab order (vertices sorted along the pore axis: half-bandwidth ~183 node blocks = ~1,650 scalars on L_50_R_5)
+    factored and solved by LAPACK dgbsv through scipy.linalg.solve_banded with the BLAS threads the box offers.  The answer is
+    checked against SuperLU's.  Reference: MUMPS (3D:792), which is multi-frontal and threaded; this is the stand-in that uses the
+    box's cores.  Capped at 4 GiB of band storage."""
+    import scipy.linalg as sla
+    import scipy.sparse.linalg as spla
+    from threadpoolctl import threadpool_limits
+    from gmpnp_amd.backend import slab_permutation
+    t0 = time.perf_counter()
+    b, A = O.assemble(prob, u0, un)
+    t_asm = time.perf_counter() - t0
+    nf, nv = prob.nf, prob.coords.shape[0]
+    perm = slab_permutation(prob.coords, prob.cells, window=0)      # internal position -> file vertex
+    pos = np.empty(nv, dtype=np.int64)
+    pos[perm] = np.arange(nv)
+    dof_new = (pos[:, None] * nf + np.arange(nf)[None, :]).ravel()   # file dof -> band dof
+    C = A.tocoo()
+    r, c = dof_new[C.row], dof_new[C.col]
+    kl = int((r - c).max())
+    ku = int((c - r).max())
+    n = A.shape[0]
+    if (2 * kl + ku + 1) * n * 8 > 4 * 2 ** 30:
+        return {"skipped": "band storage %.1f GiB" % ((2 * kl + ku + 1) * n * 8 / 2 ** 30)}
+    ab = np.zeros((kl + ku + 1, n))
+    ab[ku + r - c, c] = C.data
+    rhs = np.empty(n)
+    rhs[dof_new] = b
+    threads = os.cpu_count() or 1
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        x = sla.solve_banded((kl, ku), ab, rhs, overwrite_ab=True, overwrite_b=False, check_finite=False)
+        t_lu = time.perf_counter() - t0
+    xs = spla.splu(A.tocsc()).solve(b)
+    err = float(np.linalg.norm(x[dof_new] - xs) / np.linalg.norm(xs))
+    return {"threads": threads, "half_bandwidth_scalars": [kl, ku], "assembly_seconds": t_asm, "lu_seconds": t_lu,
+            "seconds_per_newton_iteration": t_asm + t_lu, "value": 1.0 / (t_asm + t_lu), "unit": "Newton-iterations/s",
+            "solution_vs_superlu": err,
+            "what": "Jacobian of time step 0, slab order, LAPACK dgbsv (scipy.linalg.solve_banded) with %d BLAS threads" % threads}
+
+
+def edl50_case(device_id, steps=100, warmup=3, cpu=True):
+    """BASELINE configs[1]: reference 1D/MPNP_CO2ER_EDL.py with its defaults (K+, 0.1 M KHCO3, MPNP, V = -1, 50 um mesh of 5,991
+    vertices, 7 fields = 41,937 dofs), the 100 dry-run steps of 1D:256-268.  A step = one Newton solve on the device (element
+    pass, gathers, block-cyclic-reduction direct solve, update) + the step glue (vertex values back, u_n.assign(u))."""
+    import torch
+    from gmpnp_amd.edl1d import EDLRun
+    run = EDLRun(device_kwargs={"device_id": device_id})
+    try:
+        assert run.tot_num_steps == 100 and run.mesh.num_vertices == 5991
+        nv = run.mesh.num_vertices
+
+        def reset():
+            run.sys.initialise([1.0] * 6 + [0.0])
+            run.history = run.history[:1]
+            run.newton_its, run.n, run.t = [], 0, 0.0
+
+        for _ in range(warmup):
+            run.step(verbose=False)
+        reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run.step(verbose=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        its = int(sum(run.newton_its))
+        dev = run.sys.dev
+        nf = dev.nf
+        nd = dev.ndof
+        # direct solve of the block-tridiagonal Jacobian: every matrix block read once, right-hand side in, solution out
+        alg_bytes = (3 * nv - 2) * nf * nf * 8 + 2 * 8 * nd
+        solve_us = dev.time_kernel(18, 50)
+        levels = int(np.ceil(np.log2(nv))) + 1
+        out = {"metric": "newton_iterations_per_sec", "value": its / dt, "unit": "Newton-iterations/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": 1e3 * dt / steps, "dtype": "f64",
+               "config": {"workload": "1D MPNP_CO2ER_EDL, 1D_variable_50um_mesh_5990, K+, 0.1 M KHCO3, V=-1: the %d dry-run steps "
+                                      "(Newton rtol=atol=1e-4, omega=1, max 50; linear solve = block cyclic reduction, direct)" % steps,
+                          "n_vertices": nv, "n_dofs": nd, "newton_iterations": its},
+               "roofline": {"bound": "hbm", "kernel": "1D direct solve: k_tri_extract + %d levels of k_bcr_forward, k_bcr_top, %d levels of "
+                                                      "k_bcr_backward (one launch each)" % (levels - 1, levels - 1),
+                            "algorithmic_bytes_per_solve": alg_bytes, "mean_solve_us": solve_us,
+                            "achieved": alg_bytes / (solve_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                            "frac": alg_bytes / (solve_us * 1e-6) / 1e9 / 8000.0, "traffic": None,
+                            "note": "a chain of ~26 dependent launches over 7.7 MB that halves at every level: launch-latency bound, "
+                                    "not bandwidth bound; timed with one HIP event pair around 50 back-to-back solves"}}
+    finally:
+        run.sys.close()
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import edl1d as OE
+        st = OE.Setup()
+        u, un = st.initial_state()
+        OE.run(st, 1, u, un)   # load / page in
+        t0 = time.perf_counter()
+        u, un, oits, done, _ = OE.run(st, steps, u, un)
+        wall = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(oits[:done].sum()) / wall, "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
+                               "sample": "the same %d steps with oracle/edl1d_oracle.c (literal Gauss-point assembly + banded LU with "
+                                         "partial pivoting, one thread): %d Newton iterations in %.2f s" % (steps, int(oits[:done].sum()), wall),
+                               "newton_iterations": int(oits[:done].sum())}
+        out["newton_iterations_equal_cpu"] = bool(int(oits[:done].sum()) == its)
+    return out
 
 
 def main():
@@ -142,6 +265,26 @@ def main():
         dist.barrier()
     from gmpnp_amd.pore3d import PoreRun
     from gmpnp_amd.problem import pore_dirichlet
+
+    if a.case == "edl50":   # BASELINE configs[1] as the headline line: N independent replicas of the 1D run (the 1D path does not shard)
+        if dist is not None:
+            dist.barrier()
+        o = edl50_case(local, steps=a.steps if a.steps != 50 else 100, warmup=a.warmup, cpu=(rank == 0 and not a.no_cpu_baseline))
+        val, ms = o["value"], o["ms_per_step"]
+        if dist is not None:
+            t = torch.tensor([ms], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t[0])
+            val = world * o["config"]["newton_iterations"] / (ms * 1e-3 * o["steps"])
+        if rank == 0:
+            o.update(value=val, ms_per_step=ms, n_gpus=world, higher_is_better=True, scaling="weak", vs_baseline=None,
+                     data="reference inputs shipped in data/utilities (1D_variable_50um_mesh_5990, parameters.yaml, bulk_soln_0.1KHCO3.yaml); deterministic, no RNG")
+            o["config"]["parallelism"] = "1 GPU" if world == 1 else "%d independent replicas (the 1D path does not shard: replicas only)" % world
+            print(json.dumps(o), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     _, Lnm, _, Rnm = a.mesh.split("_")
     common = dict(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine)
@@ -196,83 +339,143 @@ def main():
         dt, its, kry = float(t[0]), float(s[0]), float(s[1])
 
     prof = run.sys.dev.spmv_profile() if rank == 0 else None
+    final_replica = run.history[-1].copy()      # what a partitioned run of the same window must reproduce
+
+    # The complete line is built BEFORE the partitioned phase (roofline sampling, event overhead, CPU baseline, 1D case): from
+    # here on the only thing that can still change is `partitioned`, so the watchdog has nothing to compute on a GPU that may hang.
+    out = make_output(a, run, run.sys.dev, prof, nv, world, dt, its, kry) if rank == 0 else None
+    if rank == 0 and world == 1 and not a.no_edl50 and a.refine == 0:
+        try:
+            out["edl50"] = edl50_case(local, cpu=not a.no_cpu_baseline)
+        except Exception as e:  # noqa: BLE001
+            out["edl50"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    import threading
+    emit_lock = threading.Lock()
+    emitted = {"done": False}
 
     def emit(part_result):
-        print(json.dumps(make_output(a, run, run.sys.dev, prof, nv, world, dt, its, kry, part_result)), flush=True)
+        """Print THE line, once (main path and watchdog share the flag)."""
+        with emit_lock:
+            if emitted["done"] or rank != 0:
+                return
+            emitted["done"] = True
+            print(json.dumps(attach_partitioned(out, a, world, part_result)), flush=True)
 
-    # ---- N > 1: the north-star quantity — ONE problem, mesh-partitioned over the N GPUs (RCCL inside the library) ------------
+    # ---- N > 1: the north-star quantity — ONE problem, mesh-partitioned over the N GPUs -------------------------------------
     part = None
     if (world > 1 or a.force_partitioned) and not a.replicas_only:
-        import threading
-
-        state = {"best": None}
+        # the replica handle is idle from here on: without its side stream and hand-over flags nothing of it shares the card
+        state = {"best": None, "checks": {}, "phase": "start"}
 
         def bail():
-            # The RCCL path of the partitioned solve cannot be rehearsed on a one-GPU box (RCCL refuses two ranks on one
-            # device): if a transport hangs on the node, what was measured before it — another transport's rate, or the replica
-            # measurement above alone — is still reported, with the reason.
-            if rank == 0:
-                best = state["best"]
-                if best is not None:
-                    best = dict(best, note="a later transport did not finish within %d s" % a.partition_timeout)
-                emit(best or {"error": "partitioned phase did not finish within %d s" % a.partition_timeout})
-            os._exit(0)
+            # A transport that hangs between physical GPUs cannot be rehearsed on a one-GPU box.  Report what was measured before
+            # it (another transport's rate, or the replica measurement alone), which transport and phase hung, and exit NON-ZERO:
+            # the line is complete, and the driver must see that the run did not finish.
+            best = state["best"]
+            info = dict(best) if best is not None else {"error": "partitioned phase did not finish within %d s" % a.partition_timeout}
+            info["watchdog"] = "hung in %s; transport checks so far: %s" % (state["phase"], json.dumps(state["checks"]))
+            info["transport_checks"] = state["checks"]
+            emit(info)
+            sys.stdout.flush()
+            os._exit(3)
 
         wd = threading.Timer(a.partition_timeout, bail)
         wd.daemon = True
         wd.start()
         # Transports in order of preference: peer mailboxes (one kernel launch per collective: stores into the other ranks'
         # IPC-mapped mailboxes, xGMI between GPUs); RCCL inside the library; the library's host-staged transport over
-        # torch.distributed/gloo (PCIe per collective) — same algorithm in all three.  The first one that works is the headline;
-        # GMPNP_BENCH_ALL_TRANSPORTS=1 times BOTH device transports on a node and reports the faster one (not the default: a
-        # second communicator set-up in the same process is one more thing that can go wrong after a result is in hand).
+        # torch.distributed/gloo (PCIe per collective) — same algorithm in all three.  Every candidate first passes
+        # gmpnp_group_selftest (self-checking all-reduce + ghost-row messages over ITS transport, `transport_checks`); its timed run
+        # must then take the Newton iterations of the single-GPU run AND end on the single-GPU run's state (1e-8) — a transport
+        # that delivers a stale ghost row does not get to report a rate.  The first one that passes is the headline;
+        # GMPNP_BENCH_ALL_TRANSPORTS=1 times both device transports and reports the faster one.
         errors, tried = [], []
         order = ["peer"] + (["rccl"] if backend == "nccl" else []) + ["host"]
         first_only = os.environ.get("GMPNP_BENCH_ALL_TRANSPORTS", "0") in ("", "0")
         if os.environ.get("GMPNP_BENCH_TRANSPORTS"):   # rehearsal / comparison runs: e.g. "host" or "rccl,host"
             order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "rccl", "host")]
             first_only = True
+
+        def agree(flag):
+            """max over ranks of an error flag: every rank takes the same branch"""
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(int(t[0]))
+
         for transport in order:
             if state["best"] is not None and (first_only or transport == "host"):
                 break
+            check = {"selftest": None, "run": None}
+            state["checks"][transport] = check
+            prun = None
             try:
-                prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport}, **common)
+                state["phase"] = "%s: set-up" % transport
+                err = None
                 try:
-                    pdt = timed(prun)
-                    pits, pkry = float(sum(prun.newton_its)), float(prun.sys.krylov_iterations)
-                    # the partitioned run must take the Newton iterations the single-GPU run took (every rank sees the same
-                    # counts): a transport that delivers wrong bytes does not get to report a rate
-                    if world > 1 and pits != float(sum(run.newton_its)):
-                        raise RuntimeError("%d Newton iterations instead of the single-GPU run's %d" % (pits, sum(run.newton_its)))
-                    tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    res = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
-                           "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport}
-                    tried.append({"transport": transport, "value": res["value"], "krylov_iterations": pkry})
-                    if state["best"] is None or res["value"] > state["best"]["value"]:   # identical on every rank (all-reduced time)
-                        state["best"] = res
-                finally:
-                    prun.sys.close()
+                    prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport,
+                                                                           "shared_device": int(shared)}, **common)
+                except Exception as e:  # noqa: BLE001
+                    err = "%s: %s" % (type(e).__name__, str(e)[:300])
+                if agree(err is not None):
+                    raise RuntimeError(err or "another rank could not set the transport up")
+                state["phase"] = "%s: selftest" % transport
+                try:
+                    dev_err = prun.sys.ps.selftest()
+                    err = None if dev_err == 0.0 else "selftest: largest deviation %.3e" % dev_err
+                except Exception as e:  # noqa: BLE001
+                    err = "selftest: %s: %s" % (type(e).__name__, str(e)[:300])
+                check["selftest"] = "pass" if err is None else err
+                if agree(err is not None):
+                    raise RuntimeError(err or "selftest failed on another rank")
+                state["phase"] = "%s: timed run" % transport
+                pdt = timed(prun)
+                pits, pkry = float(sum(prun.newton_its)), float(prun.sys.krylov_iterations)
+                # every rank holds the same global history (all-gathered vertex values), so every rank decides alike
+                if pits != float(sum(run.newton_its)):
+                    raise RuntimeError("%d Newton iterations instead of the single-GPU run's %d" % (pits, sum(run.newton_its)))
+                rel = float(np.linalg.norm(prun.history[-1] - final_replica) / np.linalg.norm(final_replica))
+                check["state_vs_single_gpu"] = rel
+                if not rel < 1e-8:
+                    raise RuntimeError("final state differs from the single-GPU run's by %.3e (relative)" % rel)
+                tt = torch.tensor([pdt], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                res = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
+                       "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport, "state_vs_single_gpu": rel}
+                check["run"] = "pass"
+                tried.append({"transport": transport, "value": res["value"], "krylov_iterations": pkry})
+                if state["best"] is None or res["value"] > state["best"]["value"]:   # identical on every rank (all-reduced time)
+                    state["best"] = res
             except Exception as e:  # noqa: BLE001
-                errors.append("%s transport: %s: %s" % (transport, type(e).__name__, str(e)[:300]))
+                msg = "%s transport: %s: %s" % (transport, type(e).__name__, str(e)[:300])
+                errors.append(msg)
+                if check["run"] is None:
+                    check["run"] = msg
                 # every rank must take the same branch: an error on one rank only would leave the others in a collective,
-                # where the watchdog ends the phase
-        part = state["best"] if state["best"] is not None else {"error": "; ".join(errors) or "no transport"}
+                # where the watchdog ends the phase (exit code 3)
+            finally:
+                if prun is not None:
+                    try:
+                        prun.sys.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+        state["phase"] = "done"
+        part = dict(state["best"]) if state["best"] is not None else {"error": "; ".join(errors) or "no transport"}
+        part["transport_checks"] = state["checks"]
         if "value" in part:
-            part = dict(part, transports_timed=tried)
+            part["transports_timed"] = tried
             if errors:
                 part["earlier_errors"] = errors
         wd.cancel()
 
-    if rank == 0:
-        emit(part)
+    emit(part)
     run.sys.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
+def make_output(a, run, dev, prof, nv, world, dt, its, kry):
+    """Everything of the JSON line that does not depend on the partitioned phase."""
     if True:
         nb, nd = dev.n_blocks, dev.ndof
         nf = dev.nf
@@ -323,27 +526,36 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry, part):
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
                          "launches_per_krylov_iteration": launches},
         }
+        if world == 1:
+            out["scaling_note"] = "N = 1: one problem on one GPU; the field says weak because the contract has two values (at N > 1: strong = ONE problem partitioned, replicas = weak)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(run)
-        if world == 1 and part:
-            out["partitioned_rehearsal"] = part
         if world > 1:
-            replicas = {"metric": "newton_iterations_per_sec, %d independent L_50_R_5 problems, one per GPU (BASELINE configs[4] mapping)" % world,
-                        "value": its / dt, "ms_per_step": 1e3 * dt / a.steps, "newton_iterations": its, "krylov_iterations": kry, "scaling": "weak"}
-            if part and "value" in part:
-                # the headline at N > 1: ONE problem on N GPUs (strong scaling; Newton iterations counted once)
-                out.update(value=part["value"], ms_per_step=part["ms_per_step"], scaling="strong")
-                out["config"].update(newton_iterations=part["newton_iterations"], krylov_iterations=part["krylov_iterations"],
-                                     parallelism="ONE problem, %d z-slab mesh partitions, one per rank: ghost-row exchange + one fused all-reduce per "
-                                                 "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
-                                                 % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
-                out["roofline"]["note"] = "kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)"
-                out["replicas"] = replicas
-                out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "transports_timed", "earlier_errors", "note") if k in part}
-            else:
-                out["replicas"] = replicas
-                out["partitioned"] = part or {"error": "not run (--replicas-only)"}
+            out["replicas"] = {"metric": "newton_iterations_per_sec, %d independent L_50_R_5 problems, one per GPU (BASELINE configs[4] mapping)" % world,
+                               "value": its / dt, "ms_per_step": 1e3 * dt / a.steps, "newton_iterations": its, "krylov_iterations": kry, "scaling": "weak"}
         return out
+
+
+def attach_partitioned(out, a, world, part):
+    """The line with the result of the partitioned phase attached (pure dictionary work: also run by the watchdog)."""
+    out = dict(out)
+    if world == 1:
+        if part:
+            out["partitioned_rehearsal"] = part
+        return out
+    if part and "value" in part:
+        # the headline at N > 1: ONE problem on N GPUs (strong scaling; Newton iterations counted once)
+        out.update(value=part["value"], ms_per_step=part["ms_per_step"], scaling="strong")
+        out["config"] = dict(out["config"], newton_iterations=part["newton_iterations"], krylov_iterations=part["krylov_iterations"],
+                             parallelism="ONE problem, %d z-slab mesh partitions, one per rank: ghost-row exchange + one fused all-reduce per "
+                                         "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
+                                         % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
+        out["roofline"] = dict(out["roofline"], note="kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)")
+        out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "transports_timed", "earlier_errors", "note", "transport_checks",
+                                                   "state_vs_single_gpu", "watchdog") if k in part}
+    else:
+        out["partitioned"] = part or {"error": "not run (--replicas-only)"}
+    return out
 
 
 if __name__ == "__main__":

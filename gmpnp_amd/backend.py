@@ -27,11 +27,11 @@ EXPORTS = [
     "gmpnp_set_dirichlet", "gmpnp_set_state", "gmpnp_get_state", "gmpnp_assign_previous",
     "gmpnp_newton_solve", "gmpnp_n_fields", "gmpnp_n_dofs", "gmpnp_n_blocks", "gmpnp_jacobian_nnz",
     "gmpnp_n_aggregates", "gmpnp_krylov_launches_per_iteration", "gmpnp_assemble", "gmpnp_get_jacobian_csr", "gmpnp_spmv", "gmpnp_linear_solve",
-    "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_precond_apply", "gmpnp_event_overhead",
-    "gmpnp_set_supg", "gmpnp_set_state_device", "gmpnp_assemble_device", "gmpnp_spmv_device", "gmpnp_precond_apply_device",
+    "gmpnp_time_kernel", "gmpnp_spmv_profile", "gmpnp_event_overhead",
+    "gmpnp_set_supg",
     "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create", "gmpnp_group_create_hosted",
     "gmpnp_group_peer_begin", "gmpnp_group_peer_connect",
-    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous",
+    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous", "gmpnp_group_selftest",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
 COMM_ID_BYTES = 128
@@ -58,7 +58,7 @@ class CNewtonStats(ctypes.Structure):
                 ("n_residuals", c_int32), ("residuals", c_double * MAX_HISTORY),
                 ("krylov_per_iteration", c_int32 * MAX_HISTORY),
                 ("ms_assemble", c_double), ("ms_setup", c_double), ("ms_krylov", c_double), ("ms_total", c_double),
-                ("direct_solves", c_int32), ("pad_", c_int32)]
+                ("direct_solves", c_int32), ("steric_excursion", c_int32)]
 
 
 class CLinearStats(ctypes.Structure):
@@ -72,7 +72,7 @@ class COptions(ctypes.Structure):
                 ("krylov_batch", c_int32), ("profile_every", c_int32), ("launch_form", c_int32),
                 ("warm_start", c_int32), ("coarse_refresh", c_int32), ("progress_by_copy", c_int32),
                 ("burst_iterations", c_int32), ("phase_timing", c_int32), ("no_direct_fallback", c_int32),
-                ("warm_in_stream", c_int32), ("vector_form", c_int32), ("reserved_", c_int32 * 2), ("band_lu_max_gb", c_double)]
+                ("warm_in_stream", c_int32), ("vector_form", c_int32), ("strict_steric", c_int32), ("reserved_", c_int32 * 1), ("band_lu_max_gb", c_double)]
 
 
 class CPartition(ctypes.Structure):
@@ -140,12 +140,7 @@ def load_library(path: str = None):
     lib.gmpnp_spmv.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_linear_solve.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), c_int32, c_double, c_double,
                                        c_int32, POINTER(CLinearStats)]
-    lib.gmpnp_precond_apply.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double)]
     lib.gmpnp_set_supg.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32)]
-    lib.gmpnp_set_state_device.argtypes = [c_void_p, c_void_p, c_void_p]      # raw device addresses (tensor.data_ptr())
-    lib.gmpnp_assemble_device.argtypes = [c_void_p, c_int32, c_void_p, POINTER(c_double)]
-    lib.gmpnp_spmv_device.argtypes = [c_void_p, c_void_p, c_void_p]
-    lib.gmpnp_precond_apply_device.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
     lib.gmpnp_time_kernel.argtypes = [c_void_p, c_int32, c_int32, POINTER(c_double)]
     lib.gmpnp_spmv_profile.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]
     lib.gmpnp_event_overhead.argtypes = [c_void_p, c_int32, POINTER(c_double)]
@@ -164,6 +159,7 @@ def load_library(path: str = None):
     lib.gmpnp_group_destroy.restype = None
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
     lib.gmpnp_group_assign_previous.argtypes = [c_void_p]
+    lib.gmpnp_group_selftest.argtypes = [c_void_p, POINTER(c_double)]
     lib.gmpnp_project_gradient.argtypes = [c_void_p, POINTER(c_double), c_double, POINTER(c_double), POINTER(CLinearStats)]
     lib.gmpnp_project_cellwise.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(CLinearStats)]
     if path is None:
@@ -270,7 +266,7 @@ class DeviceSolver:
     def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, krylov_batch: int = 0,
                  profile_every: int = 0, perm: np.ndarray = None, lib=None, partition: dict = None, **options):
         """``options``: further fields of ``gmpnp_options_t`` by name (shared_device, launch_form, warm_start,
-        coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream, vector_form,
+        coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream, vector_form, strict_steric,
         band_lu_max_gb); all default to 0."""
         self.lib = lib or load_library()
         self.problem = problem
@@ -426,13 +422,6 @@ class DeviceSolver:
         return x, {"iterations": st.iterations, "converged": bool(st.converged), "residual_norm": st.residual_norm,
                    "rhs_norm": st.rhs_norm}
 
-    def precond_apply(self, r, linear_solver=LINEAR_TWOLEVEL):
-        """z = M^{-1} r with the preconditioner of the current device Jacobian."""
-        r = np.ascontiguousarray(r, dtype=np.float64)
-        z = np.empty(self.ndof)
-        self._check(self.lib.gmpnp_precond_apply(self._h, linear_solver, _dptr(r), _dptr(z)))
-        return z
-
     def project_gradient(self, f, sign=1.0):
         """``project(sign*grad(f), W).compute_vertex_values()`` for the P1 field with vertex values f (file order): (nv, dim).
         Consistent-mass L2 projection on the device (reference 1D:802-805, 3D:884-909)."""
@@ -470,20 +459,6 @@ class DeviceSolver:
 
     # ---- device-pointer variants: arguments are device addresses (e.g. ``torch.Tensor.data_ptr()`` of contiguous fp64
     # tensors of length ndof on this handle's GPU, file vertex order); the caller synchronises its own stream first ----
-    def set_state_device(self, u_ptr=None, un_ptr=None):
-        self._check(self.lib.gmpnp_set_state_device(self._h, u_ptr, un_ptr))
-
-    def assemble_device(self, F_ptr, want_jacobian=True):
-        norm = c_double()
-        self._check(self.lib.gmpnp_assemble_device(self._h, int(bool(want_jacobian)), F_ptr, byref(norm)))
-        return norm.value
-
-    def spmv_device(self, x_ptr, y_ptr):
-        self._check(self.lib.gmpnp_spmv_device(self._h, x_ptr, y_ptr))
-
-    def precond_apply_device(self, r_ptr, z_ptr, linear_solver=LINEAR_TWOLEVEL):
-        self._check(self.lib.gmpnp_precond_apply_device(self._h, linear_solver, r_ptr, z_ptr))
-
     def newton_solve(self, options: CNewtonOptions, error_on_nonconvergence=True):
         """``solve(F == 0, u, bcs, solver_parameters)`` on the device state.  Raises RuntimeError on
         non-convergence like [3P] DOLFIN (error_on_nonconvergence=True)."""
@@ -494,7 +469,7 @@ class DeviceSolver:
                  "residuals": [st.residuals[i] for i in range(st.n_residuals)],
                  "krylov_per_iteration": [st.krylov_per_iteration[i] for i in range(min(st.iterations, MAX_HISTORY))],
                  "ms_assemble": st.ms_assemble, "ms_setup": st.ms_setup, "ms_krylov": st.ms_krylov,
-                 "ms_total": st.ms_total, "direct_solves": st.direct_solves}
+                 "ms_total": st.ms_total, "direct_solves": st.direct_solves, "steric_excursion": st.steric_excursion}
         if code == ERR_NOT_CONVERGED and not error_on_nonconvergence:
             return stats
         self._check(code)
@@ -505,7 +480,7 @@ class DeviceSolver:
         return {"iterations": st.iterations, "converged": bool(st.converged), "krylov_iterations": st.krylov_iterations,
                 "residuals": [st.residuals[i] for i in range(st.n_residuals)],
                 "krylov_per_iteration": [st.krylov_per_iteration[i] for i in range(min(st.iterations, MAX_HISTORY))],
-                "ms_total": st.ms_total, "direct_solves": st.direct_solves}
+                "ms_total": st.ms_total, "direct_solves": st.direct_solves, "steric_excursion": st.steric_excursion}
 
     def time_kernel(self, kernel: int, launches: int = 50) -> float:
         us = c_double()

@@ -112,7 +112,6 @@ struct gmpnp_solver {
   int krylov_fresh_iters = 0;   // iterations of the last solve right after a coarse rebuild
   DevBuf<uint32_t> ticket;
   DevBuf<double> supg_rho;  // [nv][ns] internal order
-  DevBuf<int32_t> perm_dev;  // file vertex of each internal node (device-pointer entry points)
   bool fused_half = false;  // two launches per BiCGStab iteration (coarse workgroups inside the tile launch); opts.launch_form
   int resident_slots = 0;   // workgroups of k_half_a/b the device holds at once (occupancy query at create)
   unsigned fused_seq = 0;   // fused launches so far in the current solve
@@ -137,6 +136,7 @@ struct gmpnp_solver {
   bool x0_predicted = false;  // kx holds the predicted start of the next linear solve (left by the previous Newton update)
   bool phase_timing = false;  // opts.phase_timing fills ms_assemble / ms_setup / ms_krylov of the Newton statistics
   int direct_fallback = 1;      // opts.no_direct_fallback: a failed Krylov solve is an error again
+  int strict_steric = 0;        // opts.strict_steric: 1 - S <= 0 at a quadrature point is fatal (the reference has no such test)
   double lu_max_gb = 48.0;      // opts.band_lu_max_gb: largest band storage the fallback may allocate
   int direct_solves = 0;        // band LU solves since create (factorisations)
   int direct_sticky = 0;        // Newton solves that still go straight to the band LU after a Krylov failure
@@ -827,7 +827,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
   // Jacobian, and the separate element pass per iteration (another 43 us) is gone.  Wasted only on the last test of a solve.
   int rc = residual<DIM, NF>(s, true, &r, &flags); if (rc) return rc;
   st.ms_assemble += now_ms() - ta;
-  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  if (flags & 1) { st.steric_excursion = 1; if (s->strict_steric) return fail(GMPNP_ERR_NUMERIC, status_message(flags)); }
   const double r0 = r;
   st.residuals[0] = r; st.n_residuals = 1;
   auto conv = [&](double res) {
@@ -966,10 +966,11 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
       st.ms_setup += ms12;
       st.ms_krylov += ms23;
     }
-    if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+    if (flags & 1) { st.steric_excursion = 1; if (s->strict_steric) return fail(GMPNP_ERR_NUMERIC, status_message(flags)); }
     if (flags & 14) return fail(GMPNP_ERR_LINEAR, status_message(flags));
     if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
-    if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
+    // NaN / Inf stay fatal (DOLFIN would iterate to its limit on a NaN residual and raise there)
+    if (!(r == r) || std::isinf(r)) return fail(GMPNP_ERR_NUMERIC, (flags & 1) ? "residual became NaN / Inf after an iterate left the admissible set (1 - sum_j a_j u_j <= 0)" : "residual became NaN");
     done = conv(r);
   }
   s->state_jumped = false;
@@ -994,21 +995,6 @@ int download_vec(gmpnp_solver* s, const double* dev, double* file_order) {
   HIP_TRY(hipMemcpyAsync(s->h_stage, dev, (size_t)s->ndof * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   for (int i = 0; i < nv; ++i) std::memcpy(&file_order[(size_t)s->t.perm[i] * nf], &s->h_stage[(size_t)i * nf], nf * sizeof(double));
-  return GMPNP_OK;
-}
-
-// device-resident vectors in file order (partitioned solve: torch tensors, never staged through the host)
-int import_dev(gmpnp_solver* s, const double* file_order_dev, double* internal) {
-  hipLaunchKernelGGL(k_to_internal, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, internal, file_order_dev,
-                     (const int32_t*)s->perm_dev.p, s->nf, (int)s->ndof);
-  HIP_TRY(hipGetLastError());
-  return GMPNP_OK;
-}
-int export_dev(gmpnp_solver* s, const double* internal, double* file_order_dev) {
-  hipLaunchKernelGGL(k_to_file, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, file_order_dev, internal,
-                     (const int32_t*)s->perm_dev.p, s->nf, (int)s->ndof);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s->stream));
   return GMPNP_OK;
 }
 
@@ -1139,6 +1125,7 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
   s->burst_iters = std::max(1, po.burst_iterations);
   s->phase_timing = po.phase_timing != 0;
   s->direct_fallback = po.no_direct_fallback ? 0 : 1;
+  s->strict_steric = po.strict_steric ? 1 : 0;
   if (po.band_lu_max_gb > 0.0) s->lu_max_gb = po.band_lu_max_gb;
   if (s->coarse_async || s->warm_async) {   // the side stream exists only when something uses it
     HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
@@ -1150,7 +1137,6 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
   for (DevBuf<double>* b : {&s->cpart_v0, &s->cpart_v1, &s->cpart_t, &s->cpart_r0, &s->cpart_r1, &s->cpart_p0, &s->cpart_p1})
     HIP_TRY(b->alloc((size_t)s->ncoarse * t.tile_slots));
   HIP_TRY(s->krand.alloc(ndof));
-  HIP_TRY(s->perm_dev.upload(t.perm));
   HIP_TRY(s->ticket.alloc(16 * 66));  // counter + 64 replicated flags, one cache line each
   HIP_TRY(s->part_a.alloc((size_t)2 * t.ntiles));  // (rhat,v) partials, then ||r||^2 partials
   HIP_TRY(s->part_b.alloc((size_t)4 * t.ntiles));
@@ -1396,7 +1382,7 @@ int gmpnp_assemble(gmpnp_solver* s, int32_t want_jacobian, double* F_out, double
   }
   if (norm_out) *norm_out = r;
   if (F_out) { rc = download_vec(s, s->F.p, F_out); if (rc) return rc; }
-  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  if ((flags & 1) && s->strict_steric) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
   return GMPNP_OK;
 }
 
@@ -1484,77 +1470,9 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   return download_vec(s, s->kx.p, x);
 }
 
-int gmpnp_precond_apply(gmpnp_solver* s, int32_t mode, const double* r, double* z) {
-  if (!s || !r || !z) return fail(GMPNP_ERR_INVALID, "NULL argument");
-  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
-  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
-    return fail(GMPNP_ERR_INVALID, "preconditioner kinds: two-level or Jacobi");
-  HIP_TRY(hipSetDevice(s->opts.device_id));
-  int rc;
-  if (!s->precond_valid || s->precond_mode != mode) {
-    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
-    GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (*s->h_status & 14) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
-  }
-  rc = upload_vec(s, r, s->ky.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
-  if (rc) return rc;
-  return download_vec(s, s->kx.p, z);
-}
-
-// ---- device-pointer variants (vectors in file order, resident on the handle's device; the caller has finished writing
-// the inputs before the call, the outputs are complete at return) -------------------------------------------------------
-int gmpnp_set_state_device(gmpnp_solver* s, const double* u_dev, const double* u_n_dev) {
-  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
-  HIP_TRY(hipSetDevice(s->opts.device_id));
-  if (u_dev) { int rc = import_dev(s, u_dev, s->u.p); if (rc) return rc; s->state_jumped = true; }
-  if (u_n_dev) { int rc = import_dev(s, u_n_dev, s->un.p); if (rc) return rc; }
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  s->jacobian_valid = false;
-  return GMPNP_OK;
-}
-int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev, double* norm_out) {
-  if (!s) return fail(GMPNP_ERR_INVALID, "NULL handle");
-  int rc = gmpnp_assemble(s, want_jacobian, nullptr, norm_out);
-  if (rc) return rc;
-  return F_dev ? export_dev(s, s->F.p, F_dev) : GMPNP_OK;
-}
-int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev) {
-  if (!s || !x_dev || !y_dev) return fail(GMPNP_ERR_INVALID, "NULL argument");
-  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
-  HIP_TRY(hipSetDevice(s->opts.device_id));
-  int rc = import_dev(s, x_dev, s->kx.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_spmv_plain<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c,
-                                       (const double*)s->kx.p, s->kt.p));
-  return export_dev(s, s->kt.p, y_dev);
-}
-int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t mode, const double* r_dev, double* z_dev) {
-  if (!s || !r_dev || !z_dev) return fail(GMPNP_ERR_INVALID, "NULL argument");
-  if (!s->jacobian_valid) return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
-  if (mode != GMPNP_LINEAR_BICGSTAB_TWOLEVEL && mode != GMPNP_LINEAR_BICGSTAB_JACOBI)
-    return fail(GMPNP_ERR_INVALID, "preconditioner kinds: two-level or Jacobi");
-  HIP_TRY(hipSetDevice(s->opts.device_id));
-  int rc;
-  if (!s->precond_valid || s->precond_mode != mode) {
-    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
-    GMPNP_DISPATCH(s, rc = (setup_preconditioner<DIM, NF>(s, mode)));
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(s->h_status, s->status.p, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (*s->h_status & 14) { s->precond_valid = false; return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status)); }
-  }
-  rc = import_dev(s, r_dev, s->ky.p); if (rc) return rc;
-  GMPNP_DISPATCH(s, rc = (apply_minv<NF>(s, mode, s->ky.p, s->kx.p, 0.0, 1.0)));
-  if (rc) return rc;
-  return export_dev(s, s->kx.p, z_dev);
-}
-
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {
   if (!s || !avg_us || launches < 1) return fail(GMPNP_ERR_INVALID, "bad arguments");
-  if ((kernel == 0 || kernel == 2) && !s->jacobian_valid && kernel == 0)
+  if ((kernel == 0 || kernel == 18) && !s->jacobian_valid)
     return fail(GMPNP_ERR_INVALID, "no Jacobian assembled for the current state");
   HIP_TRY(hipSetDevice(s->opts.device_id));
   hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -1582,6 +1500,9 @@ int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double*
       case 15: GMPNP_DISPATCH(s, hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, 1)); break;
       case 16: hipLaunchKernelGGL(k_vec_a, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, 1); break;
       case 17: hipLaunchKernelGGL(k_vec_b, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, 1); break;
+      case 18:   // the whole 1D direct solve: extraction + ~13 levels of block cyclic reduction down and up (k_bcr_forward / _top / _backward)
+        if (s->dim != 1 || !s->tri_ok) return fail(GMPNP_ERR_INVALID, "kernel 18 is the 1D block-cyclic-reduction solve");
+        r = tri_solve<7>(s, s->F.p); break;
       default: return fail(GMPNP_ERR_INVALID, "unknown kernel id");
     }
     return r;

@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nve
 //   phase 1 (after half A)      out[0..1]             = sum_tile part_a, part_rr ; out[2 + w n + d] = sum_slot (v, r, p)[par]
 //   phase 2 (after half B)      out[0..3]             = sum_tile part_b[m]       ; out[4 + d]       = sum_slot cpart_t
 //   phase 3 (end of a solve)    out[d]                = sum_slot cpart_v[0][slot][d]                 (P^T y, left by k_restrict)
+// WT: the result leaves as an agent-scope write-through store (the exchange kernel: another workgroup, on any XCD, reads it
+// back in the same launch and later overwrites it — no address may be dirty in two L2s); else a plain store.
+template <bool WT = false>
 __device__ __forceinline__ void dist_reduce_block(const Ctx& c, int phase, int par, double* __restrict__ out, int o) {
   __shared__ double lds[4];
   const int n = c.ncoarse, t = threadIdx.x;
@@ -63,7 +66,10 @@ __device__ __forceinline__ void dist_reduce_block(const Ctx& c, int phase, int p
     for (int u = 0; u < 8; ++u) v[0] += (i0 + u * 256 < count) ? w8[u] : 0.0;
   }
   block_sum<1>(v, lds);
-  if (t == 0) out[o] = v[0];
+  if (t == 0) {
+    if (WT) __hip_atomic_store(out + o, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out[o] = v[0];
+  }
 }
 __global__ __launch_bounds__(256) void k_dist_reduce(const Ctx c, int phase, int par, double* __restrict__ out) {
   dist_reduce_block(c, phase, par, out, blockIdx.x);
@@ -127,7 +133,8 @@ __global__ __launch_bounds__(256) void k_zero_foreign_rows(double* __restrict__ 
 // workgroup per rank: it stores its contribution to an all-reduce into every rank's mailbox and its ghost-row messages into
 // the neighbours' (system-scope stores), fences, raises its flag in every mailbox to the exchange's sequence number, waits
 // until every rank's flag in its OWN mailbox has reached that number, sums the contributions in rank order (the same order,
-// hence the same bits, on every rank) and copies the received rows into the handle's receive buffer.  No collective library,
+// hence the same bits, on every rank) and copies the received rows into the handle's receive buffer.  The flag store is a
+// system-scope release, the end of the wait a system-scope acquire fence (one workgroup: one of each per launch).  No collective library,
 // no host step; a half-iteration of the partitioned BiCGStab costs one such launch instead of an all-reduce and a grouped
 // send/receive.  Slots alternate with the parity of the sequence number: a rank can be at most one exchange ahead of the
 // slowest (it needs everybody's flag of exchange k to finish k, and a rank raises k only after it has consumed k - 1).
@@ -146,6 +153,7 @@ struct PeerArgs {
   int n_nb, nb_rank[kPeerNbMax], send_ptr[kPeerNbMax + 1], recv_ptr[kPeerNbMax + 1];   // node offsets, as in the handle
   int peer_recv_ptr[kPeerNbMax];  // recv_ptr of THIS rank's segment in neighbour j's plan
   int32_t* err;                   // pinned host word (bit 0: a flag did not arrive within the budget)
+  unsigned long long budget;      // wall_clock64 ticks a flag may take (5 s at the device's hipDeviceAttributeWallClockRate)
 };
 __device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -168,21 +176,23 @@ __global__ __launch_bounds__(1024) void k_peer_exchange(const PeerArgs a, const 
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread: its write-through stores are out before the workgroup's flags
   __syncthreads();
+  // release / acquire at system scope, ONCE per launch (this is the only workgroup): the flag is what a peer GPU synchronises on
   if (t < a.size)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(a.box[t]) + a.me * kPeerFlagStride, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(a.box[t]) + a.me * kPeerFlagStride, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (t < a.size) {
     const unsigned* f = reinterpret_cast<const unsigned*>(a.box[a.me]) + t * kPeerFlagStride;
     const unsigned long long t0 = wall_clock64();
     // signed distance: sequence numbers may wrap
     while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
-      if (wall_clock64() - t0 > 500000000ull) {   // 5 s at 100 MHz: a rank is gone; end the launch, the host raises
+      if (wall_clock64() - t0 > a.budget) {   // 5 s: a rank is gone; end the launch, the host raises
         __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __syncthreads();   // (payload: system-scope loads of uncached memory, no acquire fence)
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope; the payload loads below are system-scope loads of uncached memory as well
   if (n_red > 0) {
     const double* mine = reinterpret_cast<const double*>(a.box[a.me] + kPeerRedOff) + (size_t)par * a.size * a.red_cap;
     for (int i = t; i < n_red; i += nt) {
@@ -214,11 +224,7 @@ __global__ __launch_bounds__(256) void k_dist_reduce_exchange(const Ctx c, int p
   __shared__ int last_flag;
   const int t = threadIdx.x, per = nvec * width, slot = a.seq & 1;
   if ((int)blockIdx.x < nout) {
-    dist_reduce_block(c, phase, par, out, blockIdx.x);   // thread 0 stored out[o]
-    if (t == 0) {   // once more, write-through: the last workgroup (any XCD) reads it back with agent-scope loads
-      const double v = out[blockIdx.x];
-      __hip_atomic_store(out + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    dist_reduce_block<true>(c, phase, par, out, blockIdx.x);   // write-through: the last workgroup (any XCD) reads it back with agent-scope loads
   } else {
     const int i = ((int)blockIdx.x - nout) * 256 + t;
     if (i < nsn * per) {
@@ -249,26 +255,27 @@ __global__ __launch_bounds__(256) void k_dist_reduce_exchange(const Ctx c, int p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // Every byte of the messages went out as a write-through system-scope store and has been waited for by its thread (the
-  // other workgroups': before their arrival at the counter): the flags follow as relaxed system-scope stores, and the
-  // receivers read flags and payload with system-scope loads of uncached memory — the "drained write-through stores, then the
-  // flag" form of the hand-over, no fence on either side.
+  // other workgroups': before their arrival at the counter).  The flags follow as RELEASE stores at system scope and the
+  // wait ends in an ACQUIRE fence — in this one workgroup only, i.e. one release and one acquire per launch (the same pair in
+  // every workgroup cost 20 us per iteration); the receivers read flags and payload with system-scope loads of uncached memory.
   if (t < a.size)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(a.box[t]) + a.me * kPeerFlagStride, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(a.box[t]) + a.me * kPeerFlagStride, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (t < a.size) {
     const unsigned* fl = reinterpret_cast<const unsigned*>(a.box[a.me]) + t * kPeerFlagStride;
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.seq) < 0) {
-      if (wall_clock64() - t0 > 500000000ull) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      if (wall_clock64() - t0 > a.budget) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __syncthreads();   // every load below is a system-scope load of uncached memory: no acquire fence
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
   {
     const double* mine = reinterpret_cast<const double*>(a.box[a.me] + kPeerRedOff) + (size_t)slot * a.size * a.red_cap;
     for (int i = t; i < nout; i += nt) {
       double acc = 0.0;
       for (int q = 0; q < a.size; ++q) acc += ld_sys(mine + (size_t)q * a.red_cap + i);
-      out[i] = acc;
+      __hip_atomic_store(out + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through too: `out` is never dirty in an L2
     }
   }
   for (int j = 0; j < a.n_nb; ++j) {

@@ -442,7 +442,7 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
   int rc = group_exchange(g, NF, 2, [](gmpnp_solver* s) { VecListW w{}; w.p[0] = s->u.p; w.p[1] = s->un.p; return w; }); if (rc) return rc;
   double r = 0.0; int flags = 0;
   rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
-  if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+  if (flags & 1) { st.steric_excursion = 1; if (g->dom[0]->strict_steric) return fail(GMPNP_ERR_NUMERIC, status_message(flags)); }
   if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual is NaN before the first Newton iteration");
   const double r0 = r;
   st.residuals[0] = r; st.n_residuals = 1;
@@ -529,10 +529,10 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
     rc = group_update<NF>(g, o.linear_solver, o.relaxation_parameter, warm); if (rc) return rc;
     st.iterations++;
     rc = group_residual<DIM, NF>(g, &r, &flags); if (rc) return rc;
-    if (flags & 1) return fail(GMPNP_ERR_NUMERIC, status_message(flags));
+    if (flags & 1) { st.steric_excursion = 1; if (g->dom[0]->strict_steric) return fail(GMPNP_ERR_NUMERIC, status_message(flags)); }
     if (flags & 14) return fail(GMPNP_ERR_LINEAR, status_message(flags));
     if (st.n_residuals < GMPNP_MAX_NEWTON_HISTORY) st.residuals[st.n_residuals++] = r;
-    if (!(r == r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN");
+    if (!(r == r) || std::isinf(r)) return fail(GMPNP_ERR_NUMERIC, "residual became NaN / Inf");
     done = conv(r);
   }
   for (gmpnp_solver* s : g->dom) { s->state_jumped = false; s->x0_predicted = false; }
@@ -710,6 +710,9 @@ int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_han
   HIP_TRY(hipHostMalloc((void**)&g->h_peer_err, sizeof(int32_t)));
   *g->h_peer_err = 0;
   a.err = g->h_peer_err;
+  int clock_khz = 0;   // wall_clock64 rate of THIS device (100 MHz on gfx950, not assumed)
+  if (hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeWallClockRate, handle->opts.device_id) != hipSuccess || clock_khz <= 0) clock_khz = 100000;
+  a.budget = 5ull * 1000ull * (unsigned long long)clock_khz;
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, g->box));
   std::memcpy(ipc_handle, &h, sizeof h);
@@ -767,6 +770,44 @@ int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* o, gm
   st = gmpnp_newton_stats_t{};
   HIP_TRY(hipSetDevice(g->dom[0]->opts.device_id));
   return group_newton<3, 9>(g, *o, st);
+}
+
+// One pass of each collective of the partitioned solve over the group's OWN transport (peer mailboxes, RCCL, host-staged or the
+// in-process copies), with contents every rank can check by itself: a 5-double all-reduce of (rank + 1)(i + 1), and a ghost-row
+// message per neighbour whose k-th value is sender * 1e6 + k.  Collective: every rank of the group calls it; *max_error = largest
+// deviation seen by THIS process.  What the bench runs before it trusts a transport between physical GPUs with a timed solve.
+int gmpnp_group_selftest(gmpnp_group* g, double* max_error) {
+  if (!g || !max_error) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(g->dom[0]->opts.device_id));
+  const int size = g->dom[0]->part_size;
+  for (gmpnp_solver* s : g->dom) {
+    double red[5];
+    for (int i = 0; i < 5; ++i) red[i] = (double)(s->part_rank + 1) * (i + 1);
+    HIP_TRY(hipMemcpyAsync(s->red_norm.p, red, sizeof red, hipMemcpyHostToDevice, s->stream));
+    const int nsn = s->send_ptr.empty() ? 0 : s->send_ptr.back();
+    std::vector<double> h((size_t)std::max(nsn, 1));
+    for (size_t j = 0; j < s->nb_rank.size(); ++j)
+      for (int k = s->send_ptr[j]; k < s->send_ptr[j + 1]; ++k) h[k] = 1e6 * s->part_rank + (k - s->send_ptr[j]);
+    if (nsn) HIP_TRY(hipMemcpyAsync(s->sendbuf.p, h.data(), (size_t)nsn * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));   // (h leaves scope)
+  }
+  int rc = group_reduce_transfer(g, [](gmpnp_solver* s) { return s->red_norm.p; }, 5, 1); if (rc) return rc;
+  double err = 0.0;
+  for (gmpnp_solver* s : g->dom) {
+    // in-process groups run every handle on dom[0]'s stream
+    double red[5];
+    HIP_TRY(hipMemcpyAsync(red, s->red_norm.p, sizeof red, hipMemcpyDeviceToHost, g->dom[0]->stream));
+    const int nrn = s->recv_ptr.empty() ? 0 : s->recv_ptr.back();
+    std::vector<double> h((size_t)std::max(nrn, 1), 0.0);
+    if (nrn) HIP_TRY(hipMemcpyAsync(h.data(), s->recvbuf.p, (size_t)nrn * sizeof(double), hipMemcpyDeviceToHost, g->dom[0]->stream));
+    HIP_TRY(hipStreamSynchronize(g->dom[0]->stream));
+    for (int i = 0; i < 5; ++i) err = std::max(err, std::fabs(red[i] - 0.5 * size * (size + 1) * (i + 1)));
+    for (size_t j = 0; j < s->nb_rank.size(); ++j)
+      for (int k = s->recv_ptr[j]; k < s->recv_ptr[j + 1]; ++k) err = std::max(err, std::fabs(h[k] - (1e6 * s->nb_rank[j] + (k - s->recv_ptr[j]))));
+  }
+  if (g->peer && *g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
+  *max_error = err;
+  return GMPNP_OK;
 }
 
 int gmpnp_group_assign_previous(gmpnp_group* g) {

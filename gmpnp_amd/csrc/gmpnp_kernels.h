@@ -1802,16 +1802,6 @@ __global__ void k_start_residual(double* __restrict__ r, const double* __restric
   if (i < n) r[i] = b[i] - w[i];
 }
 
-// file vertex order <-> internal order on the device (device-pointer entry points of the partitioned solve)
-__global__ void k_to_internal(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int nf, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int I = i / nf, f = i - I * nf; dst[i] = src[(size_t)perm[I] * nf + f]; }
-}
-__global__ void k_to_file(double* __restrict__ dst, const double* __restrict__ src, const int32_t* __restrict__ perm, int nf, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int I = i / nf, f = i - I * nf; dst[(size_t)perm[I] * nf + f] = src[i]; }
-}
-
 // deterministic pseudo-random vector in [-1, 1) (shadow vector of a BiCGStab pass that follows a breakdown)
 __global__ void k_fill_hash(double* __restrict__ v, unsigned seed, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,10 +14,9 @@ What this module is:
 * ``PartitionedSolver`` — the product path: Newton, BiCGStab, ghost exchanges and all-reduces run INSIDE libgmpnp.so
   (``gmpnp_group_newton_solve``; RCCL, in-process, or host-staged transport); Python scatters / gathers states and the
   per-step boundary values;
-* ``Comm``, ``bicgstab``, ``newton_solve``, ``DeviceLocalOps``, ``TorchDeviceLocalOps`` — round 1's host-driven form of the same
-  algorithm (one Python statement per vector operation, subdomain preconditioners without the global coarse level).  Kept as
-  the CPU rehearsal: with a NumPy test double for the three local operations it runs at world size 2 on ``gloo`` without any
-  GPU (tests/test_dist_cpu.py), which the library path cannot.  Not used by the drivers or the bench.
+* ``host_transport_callbacks`` — the two collectives of the library's host-staged transport on ``torch.distributed``.
+(Round 1's host-driven Python BiCGStab / Newton is gone from the product; tests/partition_double.py keeps a NumPy double of the
+partitioned iteration that drives ``partition_plan`` and these callbacks at world size 2 on ``gloo`` without a GPU.)
 """
 from __future__ import annotations
 
@@ -27,33 +26,6 @@ from dataclasses import dataclass
 import numpy as np
 
 from .problem import Problem
-
-
-# ---------------------------------------------------------------------------------------------
-# the solvers below work on NumPy arrays or on torch tensors (CPU or GPU) alike
-# ---------------------------------------------------------------------------------------------
-def _is_torch(a):
-    return type(a).__module__.split(".")[0] == "torch"
-
-
-def _copy(a):
-    return a.clone() if _is_torch(a) else a.copy()
-
-
-def _dot(a, b):
-    if _is_torch(a):
-        if not a.is_cuda:  # host tensors: the very arithmetic of the NumPy path
-            return float(np.dot(a.numpy(), b.numpy()))
-        import torch
-        return float(torch.dot(a, b))
-    return float(np.dot(a, b))
-
-
-def _zeros_like(a):
-    if _is_torch(a):
-        import torch
-        return torch.zeros_like(a)
-    return np.zeros_like(a)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -143,277 +115,6 @@ def build_local_domain(prob: Problem, owner: np.ndarray, rank: int, nparts: int)
             send[q] = g2l[mine]
     return LocalDomain(rank=rank, nparts=nparts, owned=owned, ghosts=ghosts, ghost_owner=gowner, problem=local,
                        n_owned=len(owned), send=send, recv=recv)
-
-
-# ---------------------------------------------------------------------------------------------
-# communication
-# ---------------------------------------------------------------------------------------------
-class Comm:
-    """Thin wrapper over torch.distributed (or a serial no-op) working on numpy vectors."""
-
-    def __init__(self, dom: LocalDomain, device=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.dom = dom
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.device = device if device is not None else "cpu"
-        self._idx_cache = {}
-
-    def allreduce_sum(self, values):
-        a = np.asarray(values, dtype=np.float64)
-        if not self.active:
-            return a.copy()
-        t = self.torch.from_numpy(a.copy()).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
-
-    def _index(self, idx, device):
-        key = (id(idx), str(device))
-        if key not in self._idx_cache:
-            self._idx_cache[key] = self.torch.as_tensor(np.asarray(idx), dtype=self.torch.long, device=device)
-        return self._idx_cache[key]
-
-    def _exchange_torch(self, x):
-        """Same plan on a torch tensor: gather the send rows on the tensor's device, move them only if the communication
-        backend needs another device (gloo: host; nccl = RCCL: none), scatter the received rows back."""
-        nf = self.dom.nf
-        x2 = x.view(-1, nf)
-        ops, bufs = [], []
-        for q, idx in sorted(self.dom.send.items()):
-            t = x2.index_select(0, self._index(idx, x.device)).to(self.device).contiguous()
-            ops.append(self.dist.P2POp(self.dist.isend, t, q))
-        for q, idx in sorted(self.dom.recv.items()):
-            t = self.torch.empty((len(idx), nf), dtype=self.torch.float64, device=self.device)
-            bufs.append((idx, t))
-            ops.append(self.dist.P2POp(self.dist.irecv, t, q))
-        if ops:
-            for r in self.dist.batch_isend_irecv(ops):
-                r.wait()
-        for idx, t in bufs:
-            x2.index_copy_(0, self._index(idx, x.device), t.to(x.device))
-        return x
-
-    def exchange(self, x):
-        """Overwrite the ghost entries of the local vector x (n_local*nf) with the owners' values."""
-        if not self.active:
-            return x
-        if _is_torch(x):
-            return self._exchange_torch(x)
-        nf = self.dom.nf
-        x2 = x.reshape(-1, nf)
-        ops, bufs = [], []
-        for q, idx in sorted(self.dom.send.items()):
-            t = self.torch.from_numpy(np.ascontiguousarray(x2[idx])).to(self.device)
-            ops.append(self.dist.P2POp(self.dist.isend, t, q))
-        for q, idx in sorted(self.dom.recv.items()):
-            t = self.torch.empty((len(idx), nf), dtype=self.torch.float64, device=self.device)
-            bufs.append((idx, t))
-            ops.append(self.dist.P2POp(self.dist.irecv, t, q))
-        if ops:
-            for r in self.dist.batch_isend_irecv(ops):
-                r.wait()
-        for idx, t in bufs:
-            x2[idx] = t.cpu().numpy()
-        return x
-
-
-# ---------------------------------------------------------------------------------------------
-# local operations on the device (the CPU tests substitute a test double with the same three methods)
-# ---------------------------------------------------------------------------------------------
-class DeviceLocalOps:
-    def __init__(self, dom: LocalDomain, linear_solver=0, **device_kwargs):
-        from . import backend
-        self.backend = backend
-        self.dev = backend.DeviceSolver(dom.problem, **device_kwargs)
-        self.mode = linear_solver
-
-    def assemble(self, u, un, want_jacobian):
-        self.dev.set_state(u, un)
-        F, _ = self.dev.assemble(want_jacobian)
-        return F
-
-    def spmv(self, x):
-        return self.dev.spmv(x)
-
-    def precond(self, r):
-        return self.dev.precond_apply(r, self.mode)
-
-    def close(self):
-        self.dev.close()
-
-
-class TorchDeviceLocalOps:
-    """The same three operations on torch tensors that live on the handle's GPU: nothing crosses the host.  Vectors are
-    contiguous fp64 tensors of length n_local*nf in the local (file) vertex order; the library reads/writes them through
-    their device addresses (``gmpnp_*_device``) on its own stream, so the torch stream is drained before each call."""
-
-    def __init__(self, dom: LocalDomain, linear_solver=0, device_id=0, **device_kwargs):
-        import torch
-        from . import backend
-        self.torch, self.backend = torch, backend
-        self.device = torch.device("cuda", device_id)
-        self.dev = backend.DeviceSolver(dom.problem, device_id=device_id, **device_kwargs)
-        self.mode = linear_solver
-
-    def tensor(self, a):
-        """NumPy -> resident tensor (set-up and tests only)."""
-        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
-
-    def _ready(self, *ts):
-        for t in ts:
-            assert t.is_cuda and t.dtype == self.torch.float64 and t.is_contiguous() and t.numel() == self.dev.ndof
-        self.torch.cuda.current_stream(self.device).synchronize()
-
-    def assemble(self, u, un, want_jacobian):
-        F = self.torch.empty_like(u)
-        self._ready(u, un, F)
-        self.dev.set_state_device(u.data_ptr(), un.data_ptr())
-        self.dev.assemble_device(F.data_ptr(), want_jacobian)
-        return F
-
-    def spmv(self, x):
-        y = self.torch.empty_like(x)
-        self._ready(x, y)
-        self.dev.spmv_device(x.data_ptr(), y.data_ptr())
-        return y
-
-    def precond(self, r):
-        z = self.torch.empty_like(r)
-        self._ready(r, z)
-        self.dev.precond_apply_device(r.data_ptr(), z.data_ptr(), self.mode)
-        return z
-
-    def close(self):
-        self.dev.close()
-
-
-# ---------------------------------------------------------------------------------------------
-# distributed BiCGStab + Newton
-# ---------------------------------------------------------------------------------------------
-def bicgstab(ops, comm: Comm, dom: LocalDomain, b, rtol=1e-10, atol=0.0, maxit=10000):
-    """Right-preconditioned BiCGStab on the owned dofs; returns (x_local incl. ghosts, iterations, converged)."""
-    own = dom.owned_dofs()
-    n = len(b)
-
-    def dots(pairs):
-        return comm.allreduce_sum([_dot(a[own], c[own]) for a, c in pairs])
-
-    def apply(p):
-        """A M^{-1} p on owned rows (ghost entries of the result are zeroed)."""
-        pin = _copy(p)
-        pin[own.stop:] = 0.0
-        z = ops.precond(pin)
-        z[own.stop:] = 0.0
-        comm.exchange(z)
-        y = ops.spmv(z)
-        y[own.stop:] = 0.0
-        return y, z
-
-    r = _copy(b)
-    r[own.stop:] = 0.0
-    rhat = _copy(r)
-    bnorm = np.sqrt(dots([(r, r)])[0])
-    tol = max(rtol * bnorm, atol)
-    y = _zeros_like(b)
-    if not bnorm > 0.0:
-        return _zeros_like(b), 0, True
-    rho = bnorm * bnorm
-    p = _copy(r)
-    it = 0
-    tiny = np.finfo(np.float64).tiny
-
-    def restart():
-        """BiCGStab breakdown ((rhat,v) ~ 0 or omega ~ 0): true residual, new shadow vector."""
-        nonlocal r, rhat, p, rho
-        Ay, _ = apply(y)
-        r = b - Ay
-        r[own.stop:] = 0.0
-        rhat = _copy(r)
-        p = _copy(r)
-        rho = dots([(r, r)])[0]
-        return np.sqrt(rho) <= tol
-
-    while True:
-        if it >= maxit:
-            return None, it, False
-        v, _ = apply(p)
-        rv = dots([(rhat, v)])[0]
-        if abs(rv) <= 1e-14 * abs(rho) or abs(rho) <= tiny:
-            it += 1
-            if restart():
-                break
-            continue
-        alpha = rho / rv
-        s = r - alpha * v
-        if np.sqrt(dots([(s, s)])[0]) <= tol:  # converged at the half step (exact subdomain solves get here)
-            y += alpha * p
-            it += 1
-            break
-        t, _ = apply(s)
-        ts, tt, rs, rt = dots([(t, s), (t, t), (rhat, s), (rhat, t)])
-        omega = ts / tt
-        y += alpha * p + omega * s
-        r = s - omega * t
-        it += 1
-        rr = dots([(r, r)])[0]
-        if np.sqrt(rr) <= tol:
-            break
-        rho_new = rs - omega * rt
-        if abs(omega) <= 1e-14 or abs(rho_new) <= 1e-14 * abs(rho) * abs(omega):
-            if restart():
-                break
-            continue
-        beta = (rho_new / rho) * (alpha / omega)
-        p = r + beta * (p - omega * v)
-        rho = rho_new
-    yin = _copy(y)
-    yin[own.stop:] = 0.0
-    x = ops.precond(yin)
-    x[own.stop:] = 0.0
-    comm.exchange(x)
-    return x, it, True
-
-
-def newton_solve(ops, comm: Comm, dom: LocalDomain, u, un, maximum_iterations=50, relative_tolerance=1e-4,
-                 absolute_tolerance=1e-4, relaxation_parameter=1.0, krylov_rtol=1e-10, krylov_maxit=10000,
-                 error_on_nonconvergence=True):
-    """[3P] dolfin::NewtonSolver semantics (SURVEY §3.3) on a partitioned state; u, un are local (owned+ghost)."""
-    own = dom.owned_dofs()
-    u = comm.exchange(_copy(u))
-    un = comm.exchange(_copy(un))
-
-    def residual(want_j):
-        F = ops.assemble(u, un, want_j)
-        F[own.stop:] = 0.0
-        return F, float(np.sqrt(comm.allreduce_sum([_dot(F[own], F[own])])[0]))
-
-    stats = {"iterations": 0, "residuals": [], "krylov_per_iteration": [], "converged": False}
-    b, r = residual(False)
-    r0 = r
-    stats["residuals"].append(r)
-
-    def conv(res):
-        with np.errstate(invalid="ignore", divide="ignore"):
-            rel = np.float64(res) / np.float64(r0)
-        return bool(rel < relative_tolerance or res < absolute_tolerance)
-
-    done = conv(r)
-    while not done and stats["iterations"] < maximum_iterations:
-        b, _ = residual(True)
-        dx, kits, ok = bicgstab(ops, comm, dom, b, rtol=krylov_rtol, maxit=krylov_maxit)
-        if not ok:
-            raise RuntimeError("distributed BiCGStab did not converge (%d iterations)" % kits)
-        stats["krylov_per_iteration"].append(kits)
-        u = u - relaxation_parameter * dx
-        stats["iterations"] += 1
-        b, r = residual(False)
-        stats["residuals"].append(r)
-        done = conv(r)
-    stats["converged"] = done
-    if not done and error_on_nonconvergence:
-        raise RuntimeError("Newton solver did not converge because maximum number of iterations reached")
-    return u, stats
 
 
 # ---------------------------------------------------------------------------------------------
@@ -576,36 +277,18 @@ class PartitionedSolver:
         self._host_group = grp
 
         def view(ptr, n):
-            return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+            return np.ctypeslib.as_array(ptr, shape=(int(n),))
+
+        ar, ex = host_transport_callbacks(grp)
 
         def allreduce(_user, buf, n):
-            try:
-                tdist.all_reduce(view(buf, n), group=grp)
-                return 0
-            except Exception:  # noqa: BLE001
-                import traceback
-                traceback.print_exc()
-                return 1
+            return ar(view(buf, n))
 
         def exchange(_user, n_nb, nb_rank, s_off, s_cnt, s_buf, r_off, r_cnt, r_buf):
-            try:
-                ops, n_s, n_r = [], 0, 0
-                for j in range(n_nb):
-                    n_s = max(n_s, s_off[j] + s_cnt[j])
-                    n_r = max(n_r, r_off[j] + r_cnt[j])
-                sv, rv = view(s_buf, max(n_s, 1)), view(r_buf, max(n_r, 1))
-                for j in range(n_nb):
-                    if s_cnt[j]:
-                        ops.append(tdist.P2POp(tdist.isend, sv[s_off[j]:s_off[j] + s_cnt[j]], int(nb_rank[j]), group=grp))
-                    if r_cnt[j]:
-                        ops.append(tdist.P2POp(tdist.irecv, rv[r_off[j]:r_off[j] + r_cnt[j]], int(nb_rank[j]), group=grp))
-                for req in (tdist.batch_isend_irecv(ops) if ops else []):
-                    req.wait()
-                return 0
-            except Exception:  # noqa: BLE001
-                import traceback
-                traceback.print_exc()
-                return 1
+            n_s = max([0] + [s_off[j] + s_cnt[j] for j in range(n_nb)])
+            n_r = max([0] + [r_off[j] + r_cnt[j] for j in range(n_nb)])
+            return ex([int(nb_rank[j]) for j in range(n_nb)], [int(s_off[j]) for j in range(n_nb)], [int(s_cnt[j]) for j in range(n_nb)],
+                      view(s_buf, max(n_s, 1)), [int(r_off[j]) for j in range(n_nb)], [int(r_cnt[j]) for j in range(n_nb)], view(r_buf, max(n_r, 1)))
 
         self._cb = (backend.ALLREDUCE_FN(allreduce), backend.EXCHANGE_FN(exchange))   # keep the thunks alive
         t = backend.CHostTransport()
@@ -666,6 +349,14 @@ class PartitionedSolver:
         self._check(self.lib.gmpnp_comm_selftest(self._comm, n, byref(err)))
         return err.value
 
+    def selftest(self):
+        """One all-reduce and one ghost-row exchange with self-checking contents over this group's transport
+        (gmpnp_group_selftest; collective); returns the largest deviation this process saw (0.0 expected)."""
+        from ctypes import byref, c_double
+        err = c_double(-1.0)
+        self._check(self.lib.gmpnp_group_selftest(self._group, byref(err)))
+        return err.value
+
     def newton_solve(self, options, error_on_nonconvergence=True):
         from ctypes import byref
         st = self.backend.CNewtonStats()
@@ -704,15 +395,42 @@ class PartitionedSolver:
         self.close()
 
 
-def gather_global(comm: Comm, dom: LocalDomain, u_local, nv_global):
-    """Assemble the global (file-order) state on every rank from the owned parts (all-reduce of disjoint pieces)."""
-    nf = dom.nf
-    if _is_torch(u_local):
-        u_local = u_local.detach().cpu().numpy()
-    out = np.zeros(nv_global * nf)
-    o2 = out.reshape(nv_global, nf)
-    o2[dom.owned] = u_local.reshape(-1, nf)[:dom.n_owned]
-    return comm.allreduce_sum(out) if comm.active else out
+def host_transport_callbacks(group=None):
+    """The two collectives of ``gmpnp_host_transport_t`` on ``torch.distributed`` (any backend with CPU tensors, e.g. gloo), as
+    functions of NumPy arrays that ALIAS the caller's buffers (the library's pinned staging memory: no copies on this side):
+    ``allreduce(buf)`` sums in place over the ranks; ``exchange(nb_rank, s_off, s_cnt, s_buf, r_off, r_cnt, r_buf)`` sends
+    ``s_buf[s_off[j] : s_off[j] + s_cnt[j]]`` to neighbour j and receives ``r_buf[r_off[j] : ...]`` from it.  Both return 0, or 1
+    after printing the traceback (the library turns that into GMPNP_ERR_HIP)."""
+    import torch
+    import torch.distributed as tdist
+
+    def allreduce(buf):
+        try:
+            tdist.all_reduce(torch.from_numpy(buf), group=group)
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def exchange(nb_rank, s_off, s_cnt, s_buf, r_off, r_cnt, r_buf):
+        try:
+            sv, rv = torch.from_numpy(s_buf), torch.from_numpy(r_buf)
+            ops = []
+            for j, q in enumerate(nb_rank):
+                if s_cnt[j]:
+                    ops.append(tdist.P2POp(tdist.isend, sv[s_off[j]:s_off[j] + s_cnt[j]], int(q), group=group))
+                if r_cnt[j]:
+                    ops.append(tdist.P2POp(tdist.irecv, rv[r_off[j]:r_off[j] + r_cnt[j]], int(q), group=group))
+            for req in (tdist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            return 0
+        except Exception:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return allreduce, exchange
 
 
 def scatter_local(dom: LocalDomain, u_global):

@@ -80,7 +80,7 @@ class EDLRun:
             print("Warning:stabilization not implemented for MPNP!")
         if self.supg:  # rho_i from the previous step's potential (u_n), OH's strong residual with grad(u_H)
             rho, self.h_vertex = supg_parameters(self.mesh.coords, self.mesh.cells, self.model.z, self.history[-1][:, 6],
-                                                 self.sys.dev.project_cellwise, self.h_vertex)
+                                                 self.sys.project_cellwise, self.h_vertex)
             w = np.arange(6, dtype=np.int32)
             w[ep.species.index("OH")] = ep.species.index("H")
             self.sys.dev.set_supg(rho, w)
@@ -124,7 +124,7 @@ class EDLRun:
         (1D:802-805 projection of -grad(p), 1D:893-954 rescaling): the two quantities 1D/Stern_CO2ER.py:66-68 records."""
         ep, mesh = self.ep, self.mesh
         last = self.history[-1]
-        field = self.sys.dev.project_gradient(last[:, 6], sign=-1.0)[:, 0] * ep.thermal_voltage / ep.L_n
+        field = self.sys.project_gradient(last[:, 6], sign=-1.0)[:, 0] * ep.thermal_voltage / ep.L_n
         c_cat = last[0, 5] * ep.initial_conc[ep.cation]
         c_H = last[0, 0] * ep.initial_conc["H"]
         w = (ep.n_water[ep.cation] * c_cat + ep.n_water["H"] * c_H) * 1.0e-3
@@ -142,7 +142,7 @@ class EDLRun:
         hist = np.stack(self.history)
         names = ["H", "OH", "HCO3", "CO32", "CO2", "cat", "p"]
         Hh = {nme: hist[:, :, i] for i, nme in enumerate(names)}
-        field_values = self.sys.dev.project_gradient(hist[-1][:, 6], sign=-1.0)[:, 0]
+        field_values = self.sys.project_gradient(hist[-1][:, 6], sign=-1.0)[:, 0]
         field_values_rescaled = field_values * ep.thermal_voltage / ep.L_n
         field_OHP = field_values_rescaled[0] * 1.0e-9
         if ep.dry_run:

@@ -116,8 +116,8 @@ class PoreRun:
         # project(+-grad(u_n), W).compute_vertex_values(): flat, component-major (3D:884-909)
         grads = {}
         for i, nme in enumerate(names[:8]):
-            grads[nme] = self.sys.dev.project_gradient(last[:, i]).T.ravel()
-        field_values = self.sys.dev.project_gradient(last[:, 8], sign=-1.0).T.ravel()
+            grads[nme] = self.sys.project_gradient(last[:, i]).T.ravel()
+        field_values = self.sys.project_gradient(last[:, 8], sign=-1.0).T.ravel()
         tau_array = np.linspace(0, pp.T, self.tot_num_steps)
         np.savez(newpath + "arrays_unscaled.npz", H=H["H"], OH=H["OH"], HCO3=H["HCO3"], CO32=H["CO32"], CO2=H["CO2"],
                  CO=H["CO"], H2=H["H2"], cat=H["cat"], p=H["p"], coor=mesh.coords, tau=tau_array,

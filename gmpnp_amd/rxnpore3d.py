@@ -113,7 +113,7 @@ class RxnPoreRun:
         last = hist[-1]
         for fname, col in (("CO", 5), ("H2", 6), ("CO2", 4), ("OH", 1), ("H", 0), ("HCO3", 2), ("CO32", 3)):
             write_pvd(os.path.join(newpath, "solution_" + fname + ".pvd"), mesh.coords, mesh.cells, last[:, col], "f_" + fname)
-        grads = {nme: self.sys.dev.project_gradient(last[:, i]).T.ravel() for i, nme in enumerate(SOLVED)}
+        grads = {nme: self.sys.project_gradient(last[:, i]).T.ravel() for i, nme in enumerate(SOLVED)}
         tau_array = np.linspace(0, pp.T, self.tot_num_steps)
         np.savez(newpath + "arrays_unscaled.npz", coor=mesh.coords, tau=tau_array, **H,
                  **{nme + "_grad": grads[nme] for nme in SOLVED})

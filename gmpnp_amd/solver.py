@@ -56,6 +56,14 @@ class GMPNPSystem:
     def assign_previous(self):
         self.dev.assign_previous()
 
+    # post-processing of the reference's drivers: project(+-grad(u_X), W) (3D:884-909, 1D:802-805) and the cell-wise
+    # projections of the SUPG parameters (1D:599,651-653), on the device
+    def project_gradient(self, f, sign=1.0):
+        return self.dev.project_gradient(f, sign=sign)
+
+    def project_cellwise(self, values):
+        return self.dev.project_cellwise(values)
+
     def close(self):
         self.dev.close()
 
@@ -69,7 +77,9 @@ class PartitionedSystem:
         from .dist import PartitionedSolver
         self.problem = problem
         self.ps = PartitionedSolver(problem, nparts, rank=rank, **device_kwargs)
-        self.dev = self.ps.devs[0]
+        self.dev = self.ps.devs[0]            # this rank's LOCAL partition handle (local vertex numbering)
+        self._device_kwargs = {k: v for k, v in device_kwargs.items() if k in ("device_id",)}
+        self._post = None                     # unpartitioned handle on the global mesh, for post-processing only
         self.nv = problem.coords.shape[0]
         self.nf = problem.nf
         self.newton_iterations = 0
@@ -103,7 +113,23 @@ class PartitionedSystem:
     def assign_previous(self):
         self.ps.assign_previous()
 
+    def _post_handle(self):
+        """The projections of the drivers' output stage take GLOBAL vertex arrays: they run on an unpartitioned handle of
+        the global mesh, created on first use (every rank that writes outputs holds one; it never solves)."""
+        if self._post is None:
+            self._post = backend.DeviceSolver(self.problem, shared_device=1, **self._device_kwargs)
+        return self._post
+
+    def project_gradient(self, f, sign=1.0):
+        return self._post_handle().project_gradient(f, sign=sign)
+
+    def project_cellwise(self, values):
+        return self._post_handle().project_cellwise(values)
+
     def close(self):
+        if self._post is not None:
+            self._post.close()
+            self._post = None
         self.ps.close()
 
 

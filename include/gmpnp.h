@@ -130,7 +130,9 @@ typedef struct {
   double ms_assemble, ms_setup, ms_krylov, ms_total; /* ms_total: host wall clock of the solve; the three phases are
                                                         device times (hipEvents), filled with gmpnp_options_t.phase_timing only */
   int32_t direct_solves;        /* Newton iterations whose system the block-banded LU solved (mode 3 or fallback) */
-  int32_t pad_;
+  int32_t steric_excursion;     /* 1 = some residual evaluation of this solve met 1 - sum_j a_j u_j <= 0 at a quadrature point
+                                   (an iterate outside the admissible set).  UFL/FFC evaluate the quotient u_i/(1 - S) as it
+                                   stands (3D:534-750, 1D:457-593), so by default this is information, not an error */
 } gmpnp_newton_stats_t;
 
 typedef struct {
@@ -167,7 +169,10 @@ typedef struct {
   int32_t vector_form;    /* BiCGStab half-iterations: 2 = the tile kernels recompute p / s at their column nodes on the fly (one launch
                              per half-iteration), 1 = streaming kernels write p / s for all rows first and the tile kernels stage
                              one vector (wins when the gathers cost memory bandwidth), 0 = automatic (1 above 768 MB of matrix) */
-  int32_t reserved_[2];   /* zero */
+  int32_t strict_steric;  /* 1 = an iterate with 1 - sum_j a_j u_j <= 0 at a quadrature point ends the solve with GMPNP_ERR_NUMERIC
+                             (rounds 1-2).  0 (default) = the reference's behaviour: no such test; an iterate that overshoots
+                             and comes back converges, one that does not ends as NaN / not converged */
+  int32_t reserved_[1];   /* zero */
   double band_lu_max_gb;  /* largest band storage the direct solver may allocate; 0 = 48 */
 } gmpnp_options_t;
 
@@ -230,21 +235,6 @@ int gmpnp_spmv(gmpnp_solver* s, const double* x, double* y);
 /* Solve J x = b with the current device Jacobian (preconditioner is rebuilt). */
 int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t linear_solver, double rtol,
                        double atol, int32_t max_iterations, gmpnp_linear_stats_t* stats);
-
-/* z = M^{-1} r with the preconditioner of the current device Jacobian (node-block Jacobi [+ coarse correction]);
- * the first call after an assembly builds it.  Used by the partitioned multi-GPU driver (gmpnp_amd/dist.py), where
- * the Krylov loop runs across ranks and each rank applies its subdomain preconditioner. */
-int gmpnp_precond_apply(gmpnp_solver* s, int32_t linear_solver, const double* r, double* z);
-
-/* Device-pointer variants for the mesh-partitioned solve (gmpnp_amd/dist.py keeps its vectors as torch tensors on the
- * GPU and exchanges ghosts with RCCL): same semantics as gmpnp_set_state / gmpnp_assemble / gmpnp_spmv /
- * gmpnp_precond_apply, but every vector pointer is DEVICE memory of the handle's GPU (file vertex order). Inputs must be
- * complete before the call (synchronise the producing stream); outputs are complete at return. No reference counterpart
- * (the reference is serial). */
-int gmpnp_set_state_device(gmpnp_solver* s, const double* u_dev, const double* u_n_dev);
-int gmpnp_assemble_device(gmpnp_solver* s, int32_t want_jacobian, double* F_dev, double* residual_norm);
-int gmpnp_spmv_device(gmpnp_solver* s, const double* x_dev, double* y_dev);
-int gmpnp_precond_apply_device(gmpnp_solver* s, int32_t kind, const double* r_dev, double* z_dev);
 
 /* ---- post-processing on the device ------------------------------------------------------------
  * project(sign * grad(f), W).compute_vertex_values() of a P1 field f given by its vertex values (file order): the
@@ -333,6 +323,10 @@ void gmpnp_group_destroy(gmpnp_group* g);
  * identical on all ranks.  Linear solver: GMPNP_LINEAR_BICGSTAB_TWOLEVEL or _JACOBI. */
 int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* opts, gmpnp_newton_stats_t* stats);
 /* u_n.assign(u) on every local handle. */
+/* One pass of each collective of the partitioned solve over the group's own transport with self-checking contents (an all-reduce
+ * of 5 doubles, one ghost-row message per neighbour): *max_error = largest deviation this process saw (0 expected).  Collective:
+ * every rank calls it.  No reference counterpart (the reference is serial); it is the start-up check of BASELINE configs[3]. */
+int gmpnp_group_selftest(gmpnp_group* g, double* max_error);
 int gmpnp_group_assign_previous(gmpnp_group* g);
 
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
@@ -340,7 +334,8 @@ int gmpnp_group_assign_previous(gmpnp_group* g);
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming
  * read of the matrix buffer with 2048 / 512 / 8192 workgroups (bandwidth probes), 12/13 = the two-launch form of the
  * half-iterations (coarse workgroups inside the tile launch), 14/15 = the tile kernels of the materialised vector form,
- * 16/17 = its streaming vector updates. */
+ * 16/17 = its streaming vector updates, 18 = one whole 1D direct solve (block cyclic reduction: extraction, every level down
+ * and up; needs an assembled Jacobian). */
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us);
 /* Fused BiCGStab half-iterations (SpMV + vector updates) timed with HIP events since the last call (opts.profile_every):
  * n_sampled = half-iterations inside the timed bursts (each a run of back-to-back launches, all of them before the end of

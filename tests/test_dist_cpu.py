@@ -1,7 +1,8 @@
-"""World-size-2 gloo test of the partitioned Newton solve (gmpnp_amd/dist.py): partition, ghost exchange plan,
-distributed BiCGStab and Newton must reproduce the serial oracle iterates.  The local operations are a test double
-built on the CPU oracle (assemble / A x / subdomain LU as preconditioner); on the GPU box the same driver runs with
-`DeviceLocalOps` (tests/test_gpu_parity.py::test_partitioned_solve_matches_serial)."""
+"""World-size-2 gloo test of what the partitioned solve needs from Python (gmpnp_amd/dist.py): the partition, the plan handed
+to gmpnp_create_partition and the host-transport callbacks the library calls back into.  The Newton / BiCGStab iteration that
+drives them here is a NumPy test double (tests/partition_double.py) on the CPU oracle's local operations; the library's own
+loops (csrc/gmpnp_group.h) run in the GPU tests — two and four PROCESSES over the same callbacks among them
+(tests/test_gpu_parity.py::test_library_partitioned_solve_two_processes_on_one_card)."""
 import os
 import sys
 
@@ -9,44 +10,6 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-class OracleLocalOps:
-    def __init__(self, dom):
-        import scipy.sparse.linalg as spla
-        import gmpnp_oracle as O
-        self.O, self.spla, self.dom = O, spla, dom
-        self.A = self.lu = None
-
-    def assemble(self, u, un, want_jacobian):
-        F, A = self.O.assemble(self.dom.problem, u, un, want_jacobian=want_jacobian)
-        if want_jacobian:
-            self.A, self.lu = A, self.spla.splu(A.tocsc())
-        return F
-
-    def spmv(self, x):
-        return self.A @ x
-
-    def precond(self, r):
-        return self.lu.solve(r)
-
-
-class TorchOracleLocalOps(OracleLocalOps):
-    """The same double behind torch tensors: exercises the tensor code path of dist.bicgstab / newton_solve / Comm (the path
-    TorchDeviceLocalOps takes on the GPU) without a GPU."""
-
-    def _t(self, a):
-        import torch
-        return torch.from_numpy(np.ascontiguousarray(a))
-
-    def assemble(self, u, un, want_jacobian):
-        return self._t(super().assemble(u.numpy(), un.numpy(), want_jacobian))
-
-    def spmv(self, x):
-        return self._t(super().spmv(x.numpy()))
-
-    def precond(self, r):
-        return self._t(super().precond(r.numpy()))
 
 
 def _small_problem():
@@ -78,28 +41,30 @@ def test_partition_and_halo_plan():
         assert all(abs(q - d.rank) == 1 for d in doms for q in d.recv)
 
 
-def _worker(rank, world, port, out_dir, use_torch=False):
+def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as tdist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     tdist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import partition_double as pd
         from gmpnp_amd import dist
         prob = _small_problem()
-        nv = prob.coords.shape[0]
-        owner = dist.slab_owner(prob.coords, prob.cells, world)
-        dom = dist.build_local_domain(prob, owner, rank, world)
-        comm = dist.Comm(dom)
-        ops = TorchOracleLocalOps(dom) if use_torch else OracleLocalOps(dom)
+        nv, nf = prob.coords.shape[0], prob.nf
+        dom, perm, part = dist.partition_plan(prob, world, rank)          # what gmpnp_create_partition gets
+        n_local = dom.n_owned + len(dom.ghosts)
+        comm = pd.PlanComm(part, n_local, nf, dist.host_transport_callbacks())   # the PRODUCT's callbacks, the library's buffer layout
+        ops = pd.OracleLocalOps(dom.problem)
         # the whole first Newton solve of time step 0 (zero initial guess, as the reference)
         un = np.tile(np.r_[np.ones(8), 0.0], nv)
-        u0, un0 = dist.scatter_local(dom, np.zeros(nv * 9)), dist.scatter_local(dom, un)
-        if use_torch:
-            u0, un0 = ops._t(u0), ops._t(un0)
-        u, st = dist.newton_solve(ops, comm, dom, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-11, krylov_maxit=3000)
-        ug = dist.gather_global(comm, dom, u, nv)
+        u0, un0 = dist.scatter_local(dom, np.zeros(nv * nf)), dist.scatter_local(dom, un)
+        u, st = pd.newton_solve(ops, comm, dom.n_owned * nf, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-11, krylov_maxit=3000)
+        ug = np.zeros((nv, nf))
+        ug[dom.owned] = u.reshape(-1, nf)[:dom.n_owned]
+        ug = comm.allreduce_sum(ug.ravel())                                # disjoint owned pieces
         if rank == 0:
             np.savez(os.path.join(out_dir, "dist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
                      kits=np.array(st["krylov_per_iteration"]))
@@ -107,8 +72,7 @@ def _worker(rank, world, port, out_dir, use_torch=False):
         tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_torch", [False, True])
-def test_partitioned_newton_matches_serial_oracle(tmp_path, use_torch):
+def test_partitioned_newton_matches_serial_oracle(tmp_path):
     import socket
     import torch.multiprocessing as mp
     import gmpnp_oracle as O
@@ -116,7 +80,7 @@ def test_partitioned_newton_matches_serial_oracle(tmp_path, use_torch):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), use_torch), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "dist.npz"))
     prob = _small_problem()
     nv = prob.coords.shape[0]

@@ -76,15 +76,50 @@ def test_assembly_as_published_variant(pore10, gpu_lib):
     assert relerr(Fo, Fi) > 1e-6  # the flux terms do matter
 
 
-def test_steric_guard_reports_instead_of_nan(pore10, gpu_lib):
+def test_steric_excursion_is_information_by_default_and_fatal_on_request(pore10, gpu_lib):
+    """UFL/FFC evaluate u_i / (1 - S) as it stands (3D:534-750): a state with 1 - S <= 0 at quadrature points assembles like any
+    other (negative quotients) — and so it does here, matching the oracle; `strict_steric` brings back the rounds-1-2 error."""
     prob = pore10[2]
     u, un = random_state(prob.coords.shape[0], 8)
     u = u.reshape(-1, 9)
     u[:, 7] = 40.0  # sum_j a_j u_j > 1 everywhere
     with gpu_lib.DeviceSolver(prob) as dev:
         dev.set_state(u.ravel(), un)
+        F, _ = dev.assemble(True)
+        A = dev.jacobian_csr()
+    Fo, Ao = O.assemble(prob, u.ravel(), un)
+    assert relerr(F, Fo) < 1e-12 and frob_rel(A, Ao) < 1e-12
+    with gpu_lib.DeviceSolver(prob, strict_steric=1) as dev:
+        dev.set_state(u.ravel(), un)
         with pytest.raises(gpu_lib.GmpnpError) as ei:
             dev.assemble(True)
+        assert ei.value.code == gpu_lib.ERR_NUMERIC
+
+
+def test_newton_through_a_steric_excursion_follows_the_unguarded_oracle(gpu_lib):
+    """1 um mesh, K+, V = -6.25, first solve from the zero state: Newton's third iterate has S = 1.25 at a quadrature point and the
+    iteration then CONVERGES (8 iterations) to a root with S = 1.52 — outside the admissible set, but that is what the published
+    forms and DOLFIN's Newton do: neither has a test for it (the oracle has none either).  The product follows the oracle iterate by
+    iterate and reports the excursion in the statistics; with `strict_steric` it raises instead."""
+    from conftest import _edl
+    ep, mesh, prob = _edl(L_n=1e-6, voltage_multiplier=-6.25)
+    nv = mesh.num_vertices
+    u0, un = np.zeros(nv * 7), np.tile(np.r_[np.ones(6), 0.0], nv)
+    u_ref, st_ref = O.newton_solve(prob, u0, un, relaxation_parameter=1.0)
+    a = np.asarray(prob.model.a)
+    assert st_ref.converged and (u_ref.reshape(nv, 7)[:, :6] @ a).max() > 1.2
+    opts = gpu_lib.newton_options({"newton_solver": {"maximum_iterations": 50, "relative_tolerance": 1e-4, "absolute_tolerance": 1e-4}}, dim=1)
+    with gpu_lib.DeviceSolver(prob) as dev:
+        dev.set_state(u0, un)
+        st = dev.newton_solve(opts)
+        u = dev.get_state()
+    assert st["converged"] and st["iterations"] == st_ref.iterations and st["steric_excursion"] == 1
+    assert np.allclose(st["residuals"], st_ref.residuals, rtol=1e-5)
+    assert relerr(u, u_ref) < 1e-8
+    with gpu_lib.DeviceSolver(prob, strict_steric=1) as dev:
+        dev.set_state(u0, un)
+        with pytest.raises(gpu_lib.GmpnpError) as ei:
+            dev.newton_solve(opts)
         assert ei.value.code == gpu_lib.ERR_NUMERIC
 
 
@@ -533,6 +568,19 @@ def test_driver_outputs(tmp_path, monkeypatch, gpu_lib):
     m1 = json.load(open(os.path.join(out1, "metadata.json")))
     assert {"eps_rel_OHP", "field_OHP", "pH_OHP", "CO2_OHP_frac", "mesh_number", "mesh_structure"} <= set(m1)
     assert "/MPNP/" in out1 and out1.endswith("voltage_-1.0_H2_FE_0.2_current_10.0_H_OHP_None_cation_K")
+    # the same 3D run on two mesh partitions writes the same files: the projections of the output stage take global vertex
+    # arrays and run on an unpartitioned post-processing handle (PartitionedSystem.project_gradient), not on rank 0's local one
+    prun = pore3d.PoreRun(num_steps=2, partition=(2, None), concentration_elec=0.5, L=10e-9, R=5e-9)
+    try:
+        prun.run(verbose=False)
+        outp = prun.write_outputs(stamp="partitioned")
+    finally:
+        prun.sys.close()
+    ap = np.load(os.path.join(outp, "arrays_unscaled.npz"))
+    assert set(ap.files) == set(a.files)
+    for key in ("p", "cat", "field_values", "cat_grad", "CO2_grad"):
+        assert ap[key].shape == a[key].shape
+        assert np.abs(ap[key] - a[key]).max() <= 1e-7 * max(1.0, np.abs(a[key]).max()), key
 
 
 def test_supg_assembly_matches_oracle(edl1, gpu_lib):
@@ -814,20 +862,23 @@ def test_reference_recorded_ohp_field_and_permittivity(voltage, tmp_path, monkey
     assert abs(meta["eps_rel_OHP"] / eps - 1.0) < 0.003
 
 
-@pytest.mark.parametrize("voltage", [-2.5, -7.5])
+@pytest.mark.parametrize("voltage", sorted(STERN_OHP))
 def test_staged_schedule_reproduces_the_recorded_digits(voltage, gpu_lib):
     """The reference's FULL 1D schedule (1D:273-290: 10,000 steps of 1e-5 s, then 10,000 steps whose clock advances by
     1e-3 s while the form keeps dt = 1e-5 s) on the GPU, post-processed as the reference does (1D:802-805,
-    893-954), lands on the digits 1D/Stern_CO2ER.py:66-68 records: measured 4e-13 / 5e-14 (V = -2.5), 2e-11 / 7e-12
-    (-5), 1.5e-10 / 2e-11 (-7.5), 4e-12 / 6e-14 (-10) relative for field_OHP / eps_rel_OHP
-    (profiles/r02/stern_schedule.json; tools/stern_schedule.py runs all five).  Newton stops at 1e-4, so agreement at
-    1e-10 after 20,000 solves means the iterates themselves follow FEniCS's: forms, scaling, Gauss-Legendre rules of the
-    steric term (2 points in F, 3 in J), DOLFIN's Newton/BC semantics, the direct solve and the projection are pinned
-    for the 1D MPNP path.  V = -12.5 is not in the test: there Newton's residual wanders at 5e-4 ... 4e-3 around the
-    1e-4 relative target (oracle and GPU alike) and reaching it within 50 iterations is a lottery per step that this
-    run loses at step 6,000 of 20,000 (profiles/r02/stern_v125_probe.log)."""
+    893-954), lands on ALL FIVE vectors 1D/Stern_CO2ER.py:66-68 records: measured 1.9e-13 / 3e-14 (V = -2.5), 8e-11 / 2.5e-11
+    (-5), 4e-11 / 5e-12 (-7.5), 1.9e-11 / 3e-13 (-10), 2.6e-11 / 3e-14 (-12.5) relative for field_OHP / eps_rel_OHP
+    (profiles/r03/stern_schedule.json, tools/stern_schedule.py) — with exactly the Newton iterations the C oracle takes over
+    the same 20,000 solves (tests/golden/stern_oracle.json: 40,024 ... 40,075; 2 per solve once the layer has formed).
+    Newton stops at 1e-4, so agreement at 1e-10 after 20,000 solves means the iterates themselves follow FEniCS's: forms,
+    scaling, the 2-point Gauss-Legendre rule of the steric term in F AND in J, DOLFIN's Newton/BC semantics, the direct solve
+    and the projection are pinned for the 1D MPNP path.  (Rounds 1-2 gave J the 3-point rule of the UFL-estimate reading:
+    Newton then degenerates near steric saturation and V = -12.5 stopped at solve 6,000 — tests/test_edl1d_oracle.py.)"""
+    import json
     from gmpnp_amd.edl1d import EDLRun
     field, eps = STERN_OHP[voltage]
+    with open(os.path.join(GOLDEN, "stern_oracle.json")) as fh:
+        oracle_row = {r["voltage_multiplier"]: r for r in json.load(fh)["rows"]}[voltage]["rows"][-1]
     run = EDLRun(voltage_multiplier=voltage, dry_run=False)
     try:
         assert run.tot_num_steps == 20000
@@ -837,8 +888,10 @@ def test_staged_schedule_reproduces_the_recorded_digits(voltage, gpu_lib):
         s = run.ohp_summary()
     finally:
         run.sys.close()
-    assert abs(s["field_OHP"] / field - 1.0) < 2e-9, s
+    assert abs(s["field_OHP"] / field - 1.0) < 5e-10, s
     assert abs(s["eps_rel_OHP"] / eps - 1.0) < 2e-10, s
+    assert int(sum(run.newton_its)) == oracle_row["newton_total"] and max(run.newton_its[-1000:]) == 2
+    assert abs(s["field_OHP"] / oracle_row["field_OHP"] - 1.0) < 5e-10 and abs(s["eps_rel_OHP"] / oracle_row["eps_rel_OHP"] - 1.0) < 2e-10
 
 
 @pytest.mark.parametrize("case,nparts", [("pore10", 2), ("pore10", 4), ("pore10", 8), ("pore50", 4)])
@@ -858,6 +911,7 @@ def test_partitioned_solve_in_library_matches_serial(case, nparts, pore10, pore5
         dev.set_state(np.zeros(nv * 9), un)
         serial = dev.newton_solve(opts)
     with dist.PartitionedSolver(prob, nparts) as ps:
+        assert ps.selftest() == 0.0   # in-process transport: device copies between the handles
         ps.set_state(np.zeros(nv * 9), un)
         st = ps.newton_solve(opts)
         u = ps.get_state()
@@ -893,7 +947,7 @@ def test_config3_geometry_on_four_partitions(gpu_lib):
     for part in (None, (4, None)):
         run = PoreRun(num_steps=1, concentration_elec=1.0, L=100e-9, R=50e-9, partition=part)
         try:
-            with pytest.raises(RuntimeError, match="1 - sum_j a_j u_j <= 0"):
+            with pytest.raises(RuntimeError):   # the iterates leave the admissible set and never come back: NaN / Inf, or 50 iterations
                 run.step(verbose=False)
         finally:
             run.sys.close()
@@ -990,6 +1044,7 @@ def _library_partition_worker(rank, world, port, out_dir, transport="host"):
         prob, _ = pore_problem(pp, mesh)
         nv = mesh.num_vertices
         with dist.PartitionedSolver(prob, world, rank=rank, transport=transport) as ps:
+            assert ps.selftest() == 0.0     # gmpnp_group_selftest: self-checking all-reduce + ghost-row messages over THIS transport
             ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
             import time
             t0 = time.perf_counter()
@@ -1047,6 +1102,7 @@ def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
     nv = mesh.num_vertices
     with dist.PartitionedSolver(prob, 1, rank=0, use_torch_dist=False) as ps:
         assert ps.comm_selftest(5000) == 0.0          # grouped ncclSend/ncclRecv (to self) + ncclAllReduce: exact copies
+        assert ps.selftest() == 0.0
         ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
         st = ps.newton_solve(gpu_lib.newton_options(MUMPS_09))
         u = ps.get_state()
@@ -1063,64 +1119,6 @@ def test_partition_plans_are_refused_when_inconsistent(pore10, gpu_lib):
         gpu_lib.DeviceSolver(dom.problem, perm=perm, partition=bad)
     with pytest.raises(gpu_lib.GmpnpError, match="ascending"):
         gpu_lib.DeviceSolver(dom.problem, perm=perm[::-1].copy(), partition=part)
-
-
-def _partition_worker(rank, world, port, out_dir, resident=False):
-    import sys
-    from conftest import ROOT
-    sys.path.insert(0, ROOT)
-    import torch.distributed as tdist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    tdist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of the test box
-    try:
-        from gmpnp_amd import dist
-        from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
-        from gmpnp_amd.params import pore_parameters, utilities_dir
-        from gmpnp_amd.problem import pore_problem
-        pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
-        mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-        prob, _ = pore_problem(pp, mesh)
-        nv = mesh.num_vertices
-        owner = dist.slab_owner(prob.coords, prob.cells, world)
-        dom = dist.build_local_domain(prob, owner, rank, world)
-        comm = dist.Comm(dom)
-        # resident: vectors are torch tensors on the GPU and the library works on their device addresses
-        ops = dist.TorchDeviceLocalOps(dom) if resident else dist.DeviceLocalOps(dom)
-        try:
-            un = np.tile(np.r_[np.ones(8), 0.0], nv)
-            u0, un0 = dist.scatter_local(dom, np.zeros(nv * 9)), dist.scatter_local(dom, un)
-            if resident:
-                u0, un0 = ops.tensor(u0), ops.tensor(un0)
-            u, st = dist.newton_solve(ops, comm, dom, u0, un0, relaxation_parameter=0.9, krylov_rtol=1e-11)
-            ug = dist.gather_global(comm, dom, u, nv)
-        finally:
-            ops.close()
-        if rank == 0:
-            np.savez(os.path.join(out_dir, "dist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
-                     kits=np.array(st["krylov_per_iteration"]))
-    finally:
-        tdist.destroy_process_group()
-
-
-@pytest.mark.parametrize("resident", [False, True])
-def test_partitioned_solve_matches_serial(tmp_path, gpu_lib, resident):
-    """Two ranks (two processes on this box's single GPU, gloo for the exchange): mesh-partitioned Newton solve with the
-    HIP backend doing the local assembly / SpMV / subdomain preconditioner = the serial result (golden pore10 step 0)."""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_partition_worker, args=(2, port, str(tmp_path), resident), nprocs=2, join=True)
-    got = np.load(os.path.join(str(tmp_path), "dist.npz"))
-    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
-    assert int(got["its"]) == int(g["newton_its"][0])
-    # early iterates sit on an ill-conditioned Jacobian (u = 0): a 1e-11 Krylov residual leaves them ~1e-5 apart,
-    # the converged state agrees tightly
-    assert np.allclose(got["res"], g["residuals"][0][:len(got["res"])], rtol=1e-4)
-    assert relerr(got["u"], g["states"][0]) < 1e-6
 
 
 # ---- closed-form pins of the 3D forms (tests/closed_forms.py): the same four cases run with the oracle in tests/test_oracle_pins.py ----

@@ -15,14 +15,15 @@ from gmpnp_amd.problem import Problem, merge_dirichlet
 
 
 def _same_rule(dim):
-    q = default_quadrature(dim)
+    from gmpnp_amd.model import ufl_estimate_quadrature
+    q = ufl_estimate_quadrature(dim)
     return Quadrature(q.lam_j, q.w_j, q.lam_j, q.w_j)
 
 
 @pytest.mark.parametrize("which", ["pore", "edl", "edl_pnp"])
 def test_jacobian_is_derivative_of_residual(which, pore10, edl1):
     """Central finite differences of the element residual vs the analytic element Jacobian, with the SAME rule for
-    F and J (the reference's J rule differs from its F rule, so only then is J exactly dF/du)."""
+    F and J (here the degree-4 one; the default shares the degree-3 one)."""
     rng = np.random.default_rng(1)
     if which == "pore":
         model, dim, ns = pore10[0].model, 3, 8

@@ -1,12 +1,13 @@
 """The quadrature tables restated from FIAT (model.py::Quadrature) integrate every monomial up to their degree
-exactly: degree 3 for the residual rule, degree 4 for the Jacobian rule."""
+exactly: degree 3 for the residual rule — which the Jacobian shares (model.default_quadrature: decided by the reference's
+recorded outputs, tests/test_edl1d_oracle.py) — and degree 4 for the rule the UFL-estimate reading would give J."""
 import itertools
 import math
 
 import numpy as np
 import pytest
 
-from gmpnp_amd.model import MAX_QUAD, default_quadrature, to_cquadrature
+from gmpnp_amd.model import MAX_QUAD, default_quadrature, to_cquadrature, ufl_estimate_quadrature
 
 
 def simplex_monomial(exps):
@@ -17,8 +18,9 @@ def simplex_monomial(exps):
 
 @pytest.mark.parametrize("dim", [1, 3])
 def test_exactness(dim):
-    q = default_quadrature(dim)
-    for lam, w, deg in ((q.lam_f, q.w_f, 3), (q.lam_j, q.w_j, 4)):
+    q, qu = default_quadrature(dim), ufl_estimate_quadrature(dim)
+    assert np.array_equal(q.lam_f, q.lam_j) and np.array_equal(q.w_f, q.w_j) and np.array_equal(q.lam_f, qu.lam_f)
+    for lam, w, deg in ((q.lam_f, q.w_f, 3), (qu.lam_j, qu.w_j, 4)):
         assert abs(w.sum() - 1.0) < 1e-13 and np.allclose(lam.sum(1), 1.0, atol=1e-14)
         for exps in itertools.product(range(deg + 1), repeat=dim + 1):
             if sum(exps) > deg:
@@ -32,8 +34,10 @@ def test_exactness(dim):
 
 def test_sizes_and_c_image():
     q3, q1 = default_quadrature(3), default_quadrature(1)
-    assert (len(q3.w_f), len(q3.w_j), len(q1.w_f), len(q1.w_j)) == (5, 14, 2, 3)
+    assert (len(q3.w_f), len(q3.w_j), len(q1.w_f), len(q1.w_j)) == (5, 5, 2, 2)
     assert q3.w_f.min() < 0  # the 5-point degree-3 rule has a negative centroid weight
+    q3, q1 = ufl_estimate_quadrature(3), ufl_estimate_quadrature(1)
+    assert (len(q3.w_f), len(q3.w_j), len(q1.w_f), len(q1.w_j)) == (5, 14, 2, 3)
     c = to_cquadrature(q3)
     assert c.nq_f == 5 and c.nq_j == 14 and c.nq_j <= MAX_QUAD
     assert c.lam_j[6][1] == pytest.approx(1 - 3 * 0.1005267652252045)
