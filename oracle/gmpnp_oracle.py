@@ -18,10 +18,13 @@ PARITY STATUS: the arithmetic of the reference lives in FEniCS 2019.1.0 / PETSc 
 UMFPACK (environment.yml:21-27,78,86,110), none of which exists in /root/reference or is installed
 or installable here, and the reference has no tests.  What pins this oracle:
 * 1D MPNP path — PINNED on the only hot-path outputs the reference stores (1D/Stern_CO2ER.py:66-68, field_OHP and
-  eps_rel_OHP at five voltages): the GPU product, which reproduces this oracle's goldens step for step, run over the
-  reference's 20,000-solve staged schedule lands on the recorded digits to 4e-13 ... 1.5e-10 at four voltages
-  (profiles/r02/stern_schedule.json, tests/test_gpu_parity.py::test_staged_schedule_reproduces_the_recorded_digits); the
-  oracle itself follows the same trajectory (tests/test_oracle_pins.py; 20,000 direct solves are out of its reach).
+  eps_rel_OHP at five voltages), through its sibling: oracle/edl1d_oracle.c (an independent C restatement with literal
+  Gauss-point integrands) reproduces ALL FIVE vectors to <= 4e-11 over the reference's 20,000-solve staged schedule
+  (tests/golden/stern_oracle.json), and this oracle agrees with it on F, J (1e-12) and Newton iterates (1e-9)
+  (tests/test_edl1d_oracle.py::test_agrees_with_the_numpy_oracle); the GPU product, which reproduces this oracle's goldens
+  step for step, meets the same five vectors (tests/test_gpu_parity.py::test_staged_schedule_reproduces_the_recorded_digits).
+  Those vectors also decide the one thing the forms leave open: the Jacobian uses the residual's Gauss rule
+  (gmpnp_amd/model.py::default_quadrature, DESIGN.md section 2).
 * 3D path — **parity unpinned** by reference-held numbers (there are none).  What stands in for them: four closed-form cases of
   the 3D forms (tests/closed_forms.py: zero-flux steric-Boltzmann equilibrium for the transport terms, the Debye-Hueckel Bessel
   profile for the Poisson coupling, the literal rate equations for reactions + time term, the exact discrete wall / exit flux
@@ -30,8 +33,9 @@ or installable here, and the reference has no tests.  What pins this oracle:
   published 3D/1D integrands and parameter formulas literally (no Model tables) against element_residual_jacobian /
   facet_terms; finite-difference Jacobians, closed-form element integrals vs brute-force quadrature, the steric-Boltzmann
   equilibrium, the wall-area check of 3D/mesh_tests.py:80-85 and the L4 scalars are in tests/test_oracle*.py.  The
-  quadrature points of the rational steric term on tetrahedra follow FIAT's default degree-3 (F) / degree-4 (J) schemes
-  restated from memory of the published FIAT sources (gmpnp_amd/model.py::Quadrature): that ingredient is unpinned.
+  quadrature points of the rational steric term on tetrahedra follow FIAT's default degree-3 scheme
+  restated from memory of the published FIAT sources (gmpnp_amd/model.py::Quadrature): that ingredient is unpinned
+  (bounded at 1e-6 of the field range by tests/test_quadrature.py).
 """
 from __future__ import annotations
 
