@@ -72,6 +72,9 @@ def parse():
     p.add_argument("--case", choices=["pore50", "edl50"], default="pore50",
                    help="pore50 = BASELINE configs[2] (the headline); edl50 = BASELINE configs[1], the 1D script's 100 dry-run steps")
     p.add_argument("--no-edl50", action="store_true", help="N = 1: skip the secondary 1D measurement")
+    p.add_argument("--multilevel", action="store_true",
+                   help="with --refine R > 0: the geometric multilevel term of the preconditioner over the nested meshes (gmpnp_attach_coarse_level); "
+                        "same Newton iterates, 6x fewer BiCGStab iterations at R = 2")
     return p.parse_args()
 
 
@@ -289,7 +292,8 @@ def main():
     _, Lnm, _, Rnm = a.mesh.split("_")
     common = dict(num_steps=a.steps, concentration_elec=0.5, L=float(Lnm) * 1e-9, R=float(Rnm) * 1e-9, refine=a.refine)
     run = PoreRun(device_kwargs={"device_id": local, "shared_device": int(shared),
-                                 "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "4"))}, **common)
+                                 "profile_every": int(os.environ.get("GMPNP_BENCH_SAMPLE_EVERY", "4"))},
+                  multilevel=bool(a.multilevel and a.refine > 0), **common)
     nv = run.mesh.num_vertices
 
     def reset(r):
@@ -512,6 +516,8 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry):
             "data": "reference inputs shipped in data/utilities (%s mesh, parameters_pore.yaml, bulk_soln_0.5KHCO3.yaml); "
                     "deterministic, no RNG" % a.mesh,
             "config": {"refine": a.refine, "n_vertices": nv,
+                       "preconditioner": ("node-block Jacobi + 8 slab aggregates + geometric multilevel term over %d nested meshes (V(1,1) cycles on the coarser levels)" % (a.refine + 1))
+                       if (a.multilevel and a.refine > 0) else "node-block Jacobi + 8 slab aggregates (two-level)",
                        "workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
                                    "(Newton rtol=atol=1e-4, omega=0.9, max 50; linear solve = two-level BiCGStab to "
                                    "1e-10 relative residual)" % (a.mesh, a.steps - 1),

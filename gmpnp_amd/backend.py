@@ -31,7 +31,7 @@ EXPORTS = [
     "gmpnp_set_supg",
     "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create", "gmpnp_group_create_hosted",
     "gmpnp_group_peer_begin", "gmpnp_group_peer_connect",
-    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous", "gmpnp_group_selftest",
+    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous", "gmpnp_group_selftest", "gmpnp_attach_coarse_level",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
 COMM_ID_BYTES = 128
@@ -160,6 +160,7 @@ def load_library(path: str = None):
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
     lib.gmpnp_group_assign_previous.argtypes = [c_void_p]
     lib.gmpnp_group_selftest.argtypes = [c_void_p, POINTER(c_double)]
+    lib.gmpnp_attach_coarse_level.argtypes = [c_void_p, c_void_p, POINTER(c_int32), c_double, c_int32]
     lib.gmpnp_project_gradient.argtypes = [c_void_p, POINTER(c_double), c_double, POINTER(c_double), POINTER(CLinearStats)]
     lib.gmpnp_project_cellwise.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(CLinearStats)]
     if path is None:
@@ -421,6 +422,14 @@ class DeviceSolver:
         self._check(code)
         return x, {"iterations": st.iterations, "converged": bool(st.converged), "residual_norm": st.residual_norm,
                    "rhs_norm": st.rhs_norm}
+
+    def attach_coarse_level(self, coarse: "DeviceSolver", parents, theta: float = 2.0, sweeps: int = 4):
+        """Geometric multilevel term (gmpnp_attach_coarse_level): ``coarse`` = handle of the parent mesh, ``parents`` (nv, 2) the
+        two coarse vertices each vertex of this mesh interpolates from (equal: a copy).  The coarse handle is kept alive here."""
+        par = np.ascontiguousarray(parents, dtype=np.int32).reshape(-1, 2)
+        assert par.shape[0] * self.nf == self.ndof
+        self._check(self.lib.gmpnp_attach_coarse_level(self._h, coarse._h, _iptr(par), float(theta), int(sweeps)))
+        self._coarse_level = coarse
 
     def project_gradient(self, f, sign=1.0):
         """``project(sign*grad(f), W).compute_vertex_values()`` for the P1 field with vertex values f (file order): (nv, dim).

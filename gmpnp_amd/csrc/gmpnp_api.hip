@@ -14,6 +14,7 @@
 #include "gmpnp_kernels.h"
 #include "gmpnp_band_lu.h"
 #include "gmpnp_dist_kernels.h"
+#include "gmpnp_multilevel.h"
 
 using namespace gmpnp;
 
@@ -152,6 +153,13 @@ struct gmpnp_solver {
   DevBuf<double> sendbuf, recvbuf, red_i, red_a, red_b, red_norm;
   double* h_red = nullptr;   // pinned [8]: all-reduced ||b||^2 and status bits
   std::unique_ptr<gmpnp_projector> projector;
+  // geometric multilevel term (gmpnp_attach_coarse_level, gmpnp_multilevel.h): the link to the next-coarser level (tables in the
+  // internal orders of both handles) and this handle's buffers when it serves as a coarse level itself
+  gmpnp_solver* ml_coarse = nullptr; double ml_theta = 1.0; bool ml_is_coarse = false;
+  int ml_sweeps = 2;   // as the COARSEST level: smoothing steps per application (an intermediate level runs a V(1,1) cycle)
+  double ml_omega = 0.7;   // damping of the smoothing steps
+  DevBuf<int32_t> ml_par, ml_child_ptr, ml_child, ml_copy;
+  DevBuf<double> ml_r, ml_w, ml_z;
 
   ~gmpnp_solver() {
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -319,9 +327,14 @@ void launch_coarse_chain(gmpnp_solver* s, const Ctx& c, hipStream_t st) {
 // stream otherwise).  The chain reads vals_s and owns AP / AcPart / Ac: it is awaited (in stream order, the host does
 // not block) before the next k_scale_columns and before any chain in the main stream.
 template <int DIM, int NF>
+int ml_setup(gmpnp_solver* s);
+template <int DIM, int NF>
 int setup_preconditioner(gmpnp_solver* s, int mode, bool refresh = true, bool refresh_coarse = true, bool allow_async = false) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   if (!s->precond_valid || s->precond_mode != mode) refresh = refresh_coarse = true;
+  if constexpr (DIM == 3 && NF == 9) {
+    if (s->ml_coarse && refresh) { int rc = ml_setup<DIM, NF>(s); if (rc) return rc; }   // level Jacobians at the injected state
+  }
   if (refresh) hipLaunchKernelGGL((k_block_inverse<NF>), dim3(grid_for(s->t.nv, 4)), dim3(64), 0, s->stream, s->c);
   const bool had_chain = s->chain_in_flight;
   if (had_chain) { HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_chain, 0)); s->chain_in_flight = false; }
@@ -347,6 +360,80 @@ int setup_preconditioner(gmpnp_solver* s, int mode, bool refresh = true, bool re
   return GMPNP_OK;
 }
 
+// ---- geometric multilevel term (gmpnp_multilevel.h); every launch goes to the FINEST handle's stream ------------------------------
+template <int NF>
+int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x, const NewtonUpdate* upd = nullptr);
+template <int NF>
+int ml_level_apply(gmpnp_solver* top, gmpnp_solver* L);
+// L->ml_r holds the restricted residual r of level L; L->ml_w = S_L r, one V(1,1) cycle from x = 0 (a FIXED linear operator, as
+// BiCGStab requires) with the level's own two-level preconditioner M_L^-1 = Dinv_L (I + Ps Aci Ps^T) as the smoother:
+//     x  = w M_L^-1 r                                       pre-smoothing (w = ml_omega, damped)
+//     x += mask P S_{L+1} mask P^T (r - J_L x)              coarse-grid correction, if a coarser level is attached
+//     x += w M_L^-1 (r - J_L x)                             post-smoothing; the COARSEST level repeats it ml_sweeps - 1 times
+// Two SpMVs with the level's Jacobian per cycle (1/8 of the next finer level's each).  Scratch: the level handle's Krylov vectors
+// (it never runs a solve of its own).
+template <int NF>
+int ml_level_apply(gmpnp_solver* top, gmpnp_solver* L) {
+  hipStream_t st = top->stream, keep = L->stream;
+  const int n = (int)L->ndof;
+  const dim3 vg(grid_for(n, 256));
+  auto smooth = [&](const double* src, double scale_dst) -> int {   // ml_w = scale_dst * ml_w + omega * M_L^-1 src
+    L->stream = st;
+    const int rc = apply_minv<NF>(L, GMPNP_LINEAR_BICGSTAB_TWOLEVEL, src, L->ml_w.p, scale_dst, L->ml_omega, nullptr);
+    L->stream = keep;
+    return rc;
+  };
+  auto residual = [&]() {   // ks = r - J_L ml_w, one launch
+    hipLaunchKernelGGL((k_spmv_residual<NF>), dim3(L->t.own_ntiles), dim3(kKrylovThreads), 0, st, L->c, (const double*)L->ml_w.p, (const double*)L->ml_r.p, L->ks.p);
+  };
+  int rc = smooth(L->ml_r.p, 0.0); if (rc) return rc;
+  if (gmpnp_solver* C = L->ml_coarse) {
+    residual();
+    hipLaunchKernelGGL((k_ml_restrict<NF>), dim3(grid_for(C->ndof, 256)), dim3(256), 0, st, (const double*)L->ks.p, L->c.bcflag, (const int32_t*)L->ml_child_ptr.p,
+                       (const int32_t*)L->ml_child.p, C->c.bcflag, C->ml_r.p, (int)C->ndof);
+    rc = ml_level_apply<NF>(top, C); if (rc) return rc;
+    hipLaunchKernelGGL((k_ml_prolong_add<NF>), vg, dim3(256), 0, st, (const double*)C->ml_w.p, (const int32_t*)L->ml_par.p, L->c.bcflag, L->ml_w.p, n);
+    residual();
+    rc = smooth(L->ks.p, 1.0); if (rc) return rc;
+  } else {
+    for (int k = 1; k < L->ml_sweeps; ++k) { residual(); rc = smooth(L->ks.p, 1.0); if (rc) return rc; }
+  }
+  return GMPNP_OK;
+}
+// coarse part of T src on the finest level: leaves it in s->ml_coarse->ml_w (to be prolonged by the caller's kernel)
+template <int NF>
+int ml_correction(gmpnp_solver* s, const double* src) {
+  gmpnp_solver* C = s->ml_coarse;
+  hipLaunchKernelGGL((k_ml_restrict<NF>), dim3(grid_for(C->ndof, 256)), dim3(256), 0, s->stream, src, s->c.bcflag, (const int32_t*)s->ml_child_ptr.p,
+                     (const int32_t*)s->ml_child.p, C->c.bcflag, C->ml_r.p, (int)C->ndof);
+  return ml_level_apply<NF>(s, C);
+}
+// z = vec + theta D T vec: the operand a materialised half-iteration stages
+template <int NF>
+int ml_stage(gmpnp_solver* s, const double* vec) {
+  int rc = ml_correction<NF>(s, vec); if (rc) return rc;
+  hipLaunchKernelGGL((k_ml_stage<NF>), dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, (const double*)s->ml_coarse->ml_w.p, (const int32_t*)s->ml_par.p,
+                     vec, s->ml_z.p, s->ml_theta);
+  return GMPNP_OK;
+}
+// Once per preconditioner set-up: the state goes one level down by injection, the coarser level assembles ITS Jacobian there
+// (element kernel + gather of this library on the level's own mesh) and sets up its own two-level preconditioner — which, if a
+// still coarser level is attached to it, does the same one level further down (setup_preconditioner calls this function).
+template <int DIM, int NF>
+int ml_setup(gmpnp_solver* s) {
+  gmpnp_solver* C = s->ml_coarse;
+  hipStream_t keep = C->stream;
+  C->stream = s->stream;   // (the level handle's own stream stays unused: everything of the hierarchy is ordered in the finest handle's)
+  hipLaunchKernelGGL((k_ml_inject<NF>), dim3(grid_for(C->ndof, 256)), dim3(256), 0, s->stream, (const double*)s->u.p, (const int32_t*)s->ml_copy.p, C->u.p, (int)C->ndof);
+  int rc = launch_element<DIM, NF>(C, true);
+  if (!rc) rc = launch_jac_gather<DIM, NF>(C);
+  if (!rc) { C->jacobian_valid = true; rc = setup_preconditioner<DIM, NF>(C, GMPNP_LINEAR_BICGSTAB_TWOLEVEL, true, true, false); }
+  C->stream = keep;
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  return GMPNP_OK;
+}
+
 // One half-iteration of the fused BiCGStab: one launch (coarse workgroups inside the tile launch), two, or three.
 template <int NF, int WHICH>
 int launch_half(gmpnp_solver* s, int k) {
@@ -358,14 +445,23 @@ int launch_half(gmpnp_solver* s, int k) {
     else hipLaunchKernelGGL((k_half_b<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, target);
   } else if (s->matp) {   // materialised vectors: coarse kernel, streaming vector update, tile kernel staging one vector
     const dim3 vg(grid_for(s->ndof, 256));
+    // with a multilevel term the tile kernel stages vec + theta D T vec (ml_stage) instead of the vector k_vec_a / k_vec_b wrote
     if (WHICH == 0) {
       hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL(k_vec_a, vg, dim3(256), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      if (s->ml_coarse) {
+        if constexpr (NF == 9) { int rc = ml_stage<NF>(s, s->c.kp[k & 1]); if (rc) return rc; }
+        Ctx cc = s->c; cc.stage_a = s->ml_z.p;
+        hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, cc, k);
+      } else hipLaunchKernelGGL((k_bicg_a_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
     } else {
       hipLaunchKernelGGL((k_coarse_b<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
       hipLaunchKernelGGL(k_vec_b, vg, dim3(256), 0, s->stream, s->c, k);
-      hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
+      if (s->ml_coarse) {
+        if constexpr (NF == 9) { int rc = ml_stage<NF>(s, s->c.ks); if (rc) return rc; }
+        Ctx cc = s->c; cc.stage_b = s->ml_z.p;
+        hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, cc, k);
+      } else hipLaunchKernelGGL((k_bicg_b_mat<NF>), dim3(s->t.own_ntiles), dim3(kKrylovThreads), 0, s->stream, s->c, k);
     }
   } else if (WHICH == 0) {
     hipLaunchKernelGGL((k_coarse_a<NF>), cg, dim3(kCoarseThreads), 0, s->stream, s->c, k);
@@ -516,7 +612,7 @@ int krylov(gmpnp_solver* s, int mode, double bnorm, double rtol, double atol, in
 // dst = scale_dst*dst + scale_x * M^{-1} src,  M^{-1} = Dinv (I + P Aci P^T)
 template <int NF>
 int apply_minv(gmpnp_solver* s, int mode, const double* src, double* dst, double scale_dst, double scale_x,
-               const NewtonUpdate* upd = nullptr) {
+               const NewtonUpdate* upd) {
   s->c.use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   const bool pre = s->prereduce && s->c.use_coarse;
   if (s->c.use_coarse)
@@ -627,8 +723,15 @@ int krylov_verified(gmpnp_solver* s, int mode, double bnorm, double rtol, double
     if (usable && ls.iterations > 0) {
       // the normal end of a solve inside Newton (first pass, converged, short enough to go unchecked): the final
       // M^-1 application also applies the Newton update and leaves the predicted start of the next solve
-      const bool final_now = upd && pass == 0 && s->last_done == 1 && ls.iterations <= verify_above && bnorm > 0.0;
+      const bool final_now = upd && pass == 0 && s->last_done == 1 && ls.iterations <= verify_above && bnorm > 0.0 && !s->ml_coarse;
       int rc2 = apply_minv<NF>(s, mode, s->ky.p, s->kx.p, have_x ? 1.0 : 0.0, 1.0, final_now ? upd : nullptr); if (rc2) return rc2;
+      if constexpr (NF == 9) {
+        if (s->ml_coarse) {   // x += theta T y (the multilevel term of M^-1 applied to the Krylov solution)
+          rc2 = ml_correction<NF>(s, s->ky.p); if (rc2) return rc2;
+          hipLaunchKernelGGL((k_ml_add_solution<NF>), dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, (const double*)s->ml_coarse->ml_w.p,
+                             (const int32_t*)s->ml_par.p, s->kx.p, s->ml_theta);
+        }
+      }
       if (final_now && upd_done) *upd_done = true;
       have_x = true; random_shadow = false;
     } else if (!usable) {
@@ -782,8 +885,11 @@ int band_substitute(gmpnp_solver* s, const double* rhs, double* x) {
 
 // Direct solve of J dx = b with b in kb: dx in kx, checked and refined with the true residual (the pivoting is
 // restricted to the node blocks).  stats->residual_norm = ||b - J dx||.
+// `as_direct` (the Newton loop): an answer that is finite but misses the tolerance is RETURNED, not refused — the reference's
+// MUMPS / UMFPACK hand back whatever the factorisation gives (3D:792), and it is Newton's own residual test that judges the step;
+// st->converged = 0 says so.  The parity hook gmpnp_linear_solve keeps the strict verdict.
 template <int NF>
-int band_solve(gmpnp_solver* s, double bnorm, double rtol, double atol, gmpnp_linear_stats_t* st) {
+int band_solve(gmpnp_solver* s, double bnorm, double rtol, double atol, gmpnp_linear_stats_t* st, bool as_direct = false) {
   const double tol = std::max(rtol * bnorm, atol);
   int rc = band_factor<NF>(s); if (rc) return rc;
   rc = band_substitute<NF>(s, s->kb.p, s->kx.p); if (rc) return rc;
@@ -799,6 +905,7 @@ int band_solve(gmpnp_solver* s, double bnorm, double rtol, double atol, gmpnp_li
     if (!(rn < 0.5 * best)) break;   // attainable accuracy reached
   }
   if (st) { st->converged = (rn == rn && rn <= 1e3 * tol) ? 1 : 0; st->residual_norm = rn; st->rhs_norm = bnorm; }
+  if (as_direct && rn == rn && !std::isinf(rn)) return GMPNP_OK;
   if (!(rn == rn) || rn > 1e3 * tol) {
     char buf[200];
     snprintf(buf, sizeof buf, "block-banded LU: ||b - J x|| = %.3e after refinement, ||b|| = %.3e", rn, bnorm);
@@ -855,7 +962,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
         HIP_TRY(hipMemcpyAsync(s->kb.p, s->F.p, s->ndof * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         if (s->phase_timing) HIP_TRY(hipEventRecord(s->ev_phase[2], s->stream));
         gmpnp_linear_stats_t ls{};
-        rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ls); if (rc) return rc;
+        rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ls, true); if (rc) return rc;
         st.direct_solves++; s->x0_predicted = false;
         hipLaunchKernelGGL(k_axpy, dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->u.p, (const double*)s->kx.p,
                            -o.relaxation_parameter, (int)s->ndof);
@@ -924,7 +1031,7 @@ int newton(gmpnp_solver* s, const gmpnp_newton_options_t& o, gmpnp_newton_stats_
           const std::string why = g_err;
           HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
           gmpnp_linear_stats_t ds{};
-          rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ds);
+          rc = band_solve<NF>(s, r, o.krylov_relative_tolerance, o.krylov_absolute_tolerance, &ds, true);
           if (rc) g_err = why + "; direct fallback: " + g_err;
           else {  // back off: 8, 16, ... 256 Newton solves before BiCGStab is tried again (a failed try costs ~0.25 s)
             st.direct_solves++; s->coarse_refresh_due = true;
@@ -1468,6 +1575,46 @@ int gmpnp_linear_solve(gmpnp_solver* s, const double* b, double* x, int32_t mode
   if (*s->h_status & 14) return fail(GMPNP_ERR_LINEAR, status_message(*s->h_status));
   if (rc) return rc;
   return download_vec(s, s->kx.p, x);
+}
+
+int gmpnp_attach_coarse_level(gmpnp_solver* fine, gmpnp_solver* coarse, const int32_t* parents, double theta, int32_t sweeps) {
+  if (!fine || !coarse || !parents) return fail(GMPNP_ERR_INVALID, "NULL argument");
+  if (fine == coarse || coarse->ml_is_coarse) return fail(GMPNP_ERR_INVALID, "a level handle serves one finer level");
+  if (fine->dim != 3 || coarse->dim != 3 || fine->nf != 9 || coarse->nf != 9) return fail(GMPNP_ERR_INVALID, "multilevel term: 3D pore problems (9 fields)");
+  if (fine->partitioned || coarse->partitioned) return fail(GMPNP_ERR_INVALID, "multilevel term: unpartitioned handles");
+  if (fine->opts.device_id != coarse->opts.device_id) return fail(GMPNP_ERR_INVALID, "the levels live on one device");
+  if (!(theta > 0.0)) return fail(GMPNP_ERR_INVALID, "theta must be positive");
+  if (sweeps < 1 || sweeps > 16) return fail(GMPNP_ERR_INVALID, "sweeps: 1 ... 16");
+  const int nvf = fine->t.nv, nvc = coarse->t.nv;
+  if (nvc >= nvf) return fail(GMPNP_ERR_INVALID, "the coarse level has fewer vertices");
+  std::vector<int32_t> par((size_t)2 * nvf), copy(nvc, -1);
+  std::vector<std::vector<int32_t>> kids(nvc);
+  for (int I = 0; I < nvf; ++I) {
+    const int v = fine->t.perm[I];
+    const int a = parents[2 * v], b = parents[2 * v + 1];
+    if (a < 0 || a >= nvc || b < 0 || b >= nvc) return fail(GMPNP_ERR_INVALID, "parent vertex out of range");
+    const int Ia = coarse->t.iperm[a], Ib = coarse->t.iperm[b];
+    par[2 * I] = Ia; par[2 * I + 1] = (a == b) ? -1 : Ib;
+    if (a == b) {
+      if (copy[Ia] >= 0) return fail(GMPNP_ERR_INVALID, "two fine vertices claim to be the copy of one coarse vertex");
+      copy[Ia] = I; kids[Ia].push_back(I << 1);
+    } else { kids[Ia].push_back((I << 1) | 1); kids[Ib].push_back((I << 1) | 1); }   // ascending fine index: fixed summation order
+  }
+  std::vector<int32_t> cptr(nvc + 1, 0), clist;
+  for (int Ic = 0; Ic < nvc; ++Ic) {
+    if (copy[Ic] < 0) return fail(GMPNP_ERR_INVALID, "a coarse vertex has no copy on the fine level (the meshes are not nested)");
+    clist.insert(clist.end(), kids[Ic].begin(), kids[Ic].end());
+    cptr[Ic + 1] = (int32_t)clist.size();
+  }
+  HIP_TRY(hipSetDevice(fine->opts.device_id));
+  HIP_TRY(fine->ml_par.upload(par)); HIP_TRY(fine->ml_child_ptr.upload(cptr)); HIP_TRY(fine->ml_child.upload(clist)); HIP_TRY(fine->ml_copy.upload(copy));
+  HIP_TRY(fine->ml_z.alloc(fine->ndof));
+  HIP_TRY(coarse->ml_r.alloc(coarse->ndof)); HIP_TRY(coarse->ml_w.alloc(coarse->ndof));
+  fine->ml_coarse = coarse; fine->ml_theta = theta; coarse->ml_is_coarse = true; coarse->ml_sweeps = sweeps;
+  // the staged operand exists in the materialised vector form only (k_vec_a / k_vec_b write the vector, the tile kernels stage one)
+  fine->matp = true; fine->fused_half = false;
+  fine->precond_valid = false;
+  return GMPNP_OK;
 }
 
 int gmpnp_time_kernel(gmpnp_solver* s, int32_t kernel, int32_t launches, double* avg_us) {

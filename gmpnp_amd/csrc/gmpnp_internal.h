@@ -181,6 +181,8 @@ struct Ctx {
   double* red_i;                  // [ncoarse]          P^T r_0                                  (all-reduced over the ranks)
   double* red_a;                  // [2 + 3 ncoarse]    (rhat,v) ||r||^2 | P^T v | P^T r | P^T p
   double* red_b;                  // [4 + ncoarse]      (t,s) (t,t) (rhat,s) (rhat,t) | P^T t
+  const double* stage_a;   // materialised form with a multilevel term: what half A / half B stage instead of p_k / s_k (else nullptr)
+  const double* stage_b;
   const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722
   int32_t supg_w[GMPNP_MAX_SPECIES];  // species whose gradient enters species i's strong residual (identity except Q7)
 };

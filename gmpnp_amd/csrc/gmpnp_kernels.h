@@ -1319,7 +1319,9 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   if (!FUSED) { omega = sc->omega; beta = sc->beta; }
   const double* __restrict__ po = c.kp[par ^ 1];
   const double* __restrict__ vo = c.kv[par ^ 1];
-  const double* __restrict__ sfirst = MAT ? c.kp[par] : (first ? c.kr : c.ks);  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
+  // materialised form: the staged operand is p_k itself, or p_k + theta D T p_k when a multilevel term is attached (gmpnp_multilevel.h)
+  const double* __restrict__ matsrc = (MAT && c.stage_a) ? c.stage_a : c.kp[par];
+  const double* __restrict__ sfirst = MAT ? matsrc : (first ? c.kr : c.ks);  // k = 0: s, t, p_old, v_old do not exist yet, p_0 = r_0
   // every global request of this launch, issued together
   // two independent chains: the tile record -> matrix values / local column indices, and the tile's column list
   // (fixed stride: addressable without the record) -> operands of the staged x entries
@@ -1397,7 +1399,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    const double pj = MAT ? c.kp[par][idx] : first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
+    const double pj = MAT ? matsrc[idx] : first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
     xs[q] = pj + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
@@ -1486,7 +1488,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
     const unsigned off = ((unsigned)st_col[u] * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
-    st_r[u] = ld_off(MAT ? c.ks : c.kr, off); st_v[u] = MAT ? 0.0 : ld_off(vn, off);   // MAT: s_k was written by k_vec_b
+    st_r[u] = ld_off(MAT ? ((MAT && c.stage_b) ? c.stage_b : c.ks) : c.kr, off); st_v[u] = MAT ? 0.0 : ld_off(vn, off);   // MAT: s_k was written by k_vec_b (+ the multilevel term)
   }
   const int own_r = rows.row;  // inactive lanes: row 0
   const double* ownp = wv == 0 ? c.krhat : wv == 1 ? (MAT ? c.ks : c.kr) : vn;  // wave q requests own-row vector q (see k_bicg_a)
@@ -1528,7 +1530,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
     const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    xs[q] = (MAT ? c.ks[idx] : c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
+    xs[q] = (MAT ? ((MAT && c.stage_b) ? c.stage_b : c.ks)[idx] : c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
   red[wv][lane] = rows.dot(c, xs);
@@ -1634,8 +1636,8 @@ __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b(const Ctx c, const
 }
 
 // Plain y = A x with the UNSCALED matrix (parity hook, partitioned driver); same tiling as the Krylov kernels.
-template <int NF>
-__global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
+template <int NF, bool RES>
+__device__ __forceinline__ void spmv_plain_body(const Ctx& c, const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ out) {
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double xs[kTileCols * NF];
@@ -1656,7 +1658,16 @@ __global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, cons
   double tot = 0.0;
 #pragma unroll
   for (int q = 0; q < NW; ++q) tot += red[sl * NW + q][lane];
-  out[rows.row] = tot;
+  out[rows.row] = RES ? b[rows.row] - tot : tot;
+}
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_spmv_plain(const Ctx c, const double* __restrict__ x, double* __restrict__ out) {
+  spmv_plain_body<NF, false>(c, x, nullptr, out);
+}
+// out = b - A x in one launch (the smoothing steps of the multilevel term, gmpnp_multilevel.h)
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads) void k_spmv_residual(const Ctx c, const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ out) {
+  spmv_plain_body<NF, true>(c, x, b, out);
 }
 
 // As = A Dinv: one wave per (slice, block position) scales the NF-entry row pieces of its block by Dinv of the column node.

@@ -1,0 +1,104 @@
+// Geometric multilevel term of the preconditioner on uniformly refined meshes (round 3; no reference counterpart: the reference's
+// linear solver is a direct one, 3D:792 — this is what keeps the Krylov stand-in's iteration count from growing with 1/h).
+//
+// Red refinement gives NESTED P1 spaces: a fine vertex is a coarse vertex or the midpoint of a coarse edge, so the prolongation
+// P_l (level l <- level l+1) is "copy, or mean of the two parents", applied field by field.  The preconditioner of the library,
+//     M^-1 = Dinv (I + Ps Aci Ps^T)                       node-block Jacobi + slab-aggregate coarse space (gmpnp_kernels.h)
+// gets the additive multilevel term
+//     M^-1 += theta * T,   T = P_1 ( Dinv_1 + P_2 ( Dinv_2 + ... ) P_2^T ) P_1^T
+// with Dinv_l the inverse diagonal node blocks of the Jacobian REDISCRETISED on level l at the injected state (every level is an
+// ordinary handle of its own mesh: the element kernel and the gathers of this library assemble it; tools/multilevel_experiment.py:
+// rediscretised and Galerkin diagonal blocks give the same iteration counts).  Dirichlet dofs are masked on both sides of every
+// transfer.  In the scaled system As N y = b (As = J Dinv) the term reads N += theta * D T, D = the diagonal node blocks of J:
+// the half-iterations stage  z = vec + theta * D (T vec)  instead of vec (materialised vector form), and the solution gets
+// x += theta * T y at the end.  All kernels here are gathers: fixed summation order, bitwise repeatable.
+#pragma once
+#include "gmpnp_kernels.h"
+
+namespace gmpnp {
+
+// coarse[Ic] = fine[copy_of[Ic]]   (state injection: coarse vertices ARE fine vertices)
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_inject(const double* __restrict__ fine, const int32_t* __restrict__ copy_of, double* __restrict__ coarse, int ndof_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ndof_c) return;
+  const int I = i / NF, f = i - I * NF;
+  coarse[i] = fine[(size_t)copy_of[I] * NF + f];
+}
+
+// r_c = mask_c P^T mask_f src: one thread per coarse dof sums its children (coarse node -> fine nodes, weights 1 or 1/2) in list order
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_restrict(const double* __restrict__ src, const uint8_t* __restrict__ bc_f, const int32_t* __restrict__ child_ptr,
+                                                     const int32_t* __restrict__ child, const uint8_t* __restrict__ bc_c, double* __restrict__ dst, int ndof_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ndof_c) return;
+  const int I = i / NF, f = i - I * NF;
+  double acc = 0.0;
+  if (!bc_c[i])
+    for (int k = child_ptr[I]; k < child_ptr[I + 1]; ++k) {
+      const int code = child[k];                      // fine node << 1 | (1 = weight 1/2)
+      const size_t j = (size_t)(code >> 1) * NF + f;
+      const double v = bc_f[j] ? 0.0 : src[j];
+      acc += (code & 1) ? 0.5 * v : v;
+    }
+  dst[i] = acc;
+}
+
+// w = Dinv r (node blocks, row major [node][row][col]); rows of Dirichlet dofs are identity rows and r is zero there
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_dinv(const double* __restrict__ Dinv, const double* __restrict__ r, double* __restrict__ w, int ndof) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ndof) return;
+  const int I = i / NF;
+  const double* d = Dinv + (size_t)i * NF;
+  const double* x = r + (size_t)I * NF;
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) acc += d[j] * x[j];
+  w[i] = acc;
+}
+
+// (P w_c)_i for fine dof i: copy of a coarse vertex, or the mean of the two parents
+template <int NF>
+__device__ __forceinline__ double ml_prolonged(const double* __restrict__ wc, const int32_t* __restrict__ par, int I, int f) {
+  const int pa = par[2 * I], pb = par[2 * I + 1];
+  const double a = wc[(size_t)pa * NF + f];
+  return pb < 0 ? a : 0.5 * (a + wc[(size_t)pb * NF + f]);
+}
+// w_f += mask_f P w_c   (an intermediate level: its own Dinv term is already in w_f)
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_prolong_add(const double* __restrict__ wc, const int32_t* __restrict__ par, const uint8_t* __restrict__ bc_f,
+                                                        double* __restrict__ wf, int ndof_f) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ndof_f) return;
+  const int I = i / NF, f = i - I * NF;
+  if (!bc_f[i]) wf[i] += ml_prolonged<NF>(wc, par, I, f);
+}
+// finest level, inside the Krylov loop:  z = vec + theta * D (mask P w_c)   (D = diagonal node blocks of the UNSCALED Jacobian,
+// SELL position 0: c.vals[slice_off[s] + Iloc*NF + row + col*64])
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_stage(const Ctx c, const double* __restrict__ wc, const int32_t* __restrict__ par, const double* __restrict__ vec,
+                                                  double* __restrict__ z, double theta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.ndof) return;
+  const int I = i / NF, r = i - I * NF;
+  const int s = c.node_slice[I], Iloc = I - c.slice_node0[s];
+  const double* d = c.vals + c.slice_off[s] + Iloc * NF + r;
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const double t = c.bcflag[(size_t)I * NF + j] ? 0.0 : ml_prolonged<NF>(wc, par, I, j);
+    acc += d[(size_t)j * kWave] * t;
+  }
+  z[i] = vec[i] + theta * acc;
+}
+// finest level, end of a solve:  x += theta * mask P w_c
+template <int NF>
+__global__ __launch_bounds__(256) void k_ml_add_solution(const Ctx c, const double* __restrict__ wc, const int32_t* __restrict__ par, double* __restrict__ x, double theta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.ndof) return;
+  const int I = i / NF, f = i - I * NF;
+  if (!c.bcflag[i]) x[i] += theta * ml_prolonged<NF>(wc, par, I, f);
+}
+
+}  // namespace gmpnp

@@ -32,6 +32,9 @@ class Mesh:
     coords: np.ndarray  # (nv, dim) float64
     cells: np.ndarray  # (nc, dim+1) int32
     _facets: dict = field(default_factory=dict, repr=False)
+    # set by refine_uniform on the mesh it returns: (nv, 2) the two vertices of the PARENT mesh each vertex interpolates from
+    # (equal: the vertex is a copy of that parent vertex) — the nested-space table of the multilevel preconditioner
+    parents: np.ndarray = field(default=None, repr=False)
 
     @property
     def num_vertices(self) -> int:
@@ -263,7 +266,8 @@ def refine_uniform(mesh: Mesh):
         coords = np.concatenate([mesh.coords, mid])
         m = nv + np.arange(len(c), dtype=np.int32)
         cells = np.concatenate([np.stack([c[:, 0], m], 1), np.stack([m, c[:, 1]], 1)]).astype(np.int32)
-        return Mesh(dim=1, coords=coords, cells=cells), None
+        par = np.concatenate([np.stack([np.arange(nv), np.arange(nv)], 1), c[:, :2]]).astype(np.int32)
+        return Mesh(dim=1, coords=coords, cells=cells, parents=par), None
     pairs = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])
     e = np.sort(c[:, pairs].reshape(-1, 2), axis=1).astype(np.int64)
     key = e[:, 0] * nv + e[:, 1]
@@ -281,7 +285,8 @@ def refine_uniform(mesh: Mesh):
         a, b = np.minimum(a, b).astype(np.int64), np.maximum(a, b).astype(np.int64)
         return (nv + np.searchsorted(ukey, a * nv + b)).astype(np.int32)
 
-    return Mesh(dim=3, coords=coords, cells=cells), midpoint
+    par = np.concatenate([np.stack([np.arange(nv), np.arange(nv)], 1), edges]).astype(np.int32)
+    return Mesh(dim=3, coords=coords, cells=cells, parents=par), midpoint
 
 
 def refine_pore(mesh: Mesh, bnd: PoreBoundaries):

@@ -42,13 +42,21 @@ class PoreRun:
     """State of one pore simulation; ``step()`` is one pass of the reference's time loop body (3D:783-858)."""
 
     def __init__(self, num_steps=None, as_published=False, device_kwargs=None, solver_parameters=None, refine=0,
-                 partition=None, **kwargs):
+                 partition=None, multilevel=False, ml_theta=2.0, ml_sweeps=4, **kwargs):
         """``partition`` = (nparts, rank): solve this ONE problem across `nparts` mesh partitions (rank None: all of them in
-        this process on one GPU; rank r: this process is rank r of a ``torch.distributed`` job, RCCL inside the library)."""
+        this process on one GPU; rank r: this process is rank r of a ``torch.distributed`` job, RCCL inside the library).
+        ``multilevel`` (with ``refine`` > 0): the preconditioner gets the geometric multilevel term over the nested meshes
+        (gmpnp_attach_coarse_level) — not a reference feature; it changes iteration counts of the linear solves, not results."""
         self.kwargs = kwargs
         self.pp = pore_parameters(as_published=as_published, **kwargs)
         self.mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), self.pp.mesh_name))
-        self.problem, self.bnd = pore_problem(self.pp, self.mesh, refine=refine)
+        self._levels = None
+        if multilevel and refine > 0 and not partition:
+            from .problem import pore_hierarchy
+            self._levels = pore_hierarchy(self.pp, self.mesh, refine)
+            self.problem, self.bnd = self._levels[0][0], self._levels[0][1]
+        else:
+            self.problem, self.bnd = pore_problem(self.pp, self.mesh, refine=refine)
         if refine:  # uniformly refined copy of the reference mesh (not a reference feature: roofline studies)
             from .mesh import Mesh
             self.mesh = Mesh(dim=3, coords=self.problem.coords, cells=self.problem.cells)
@@ -57,6 +65,14 @@ class PoreRun:
             self.sys = PartitionedSystem(self.problem, partition[0], rank=partition[1], **(device_kwargs or {}))
         else:
             self.sys = GMPNPSystem(self.problem, **(device_kwargs or {}))
+            if self._levels:   # coarser levels: ordinary handles of the parent meshes, attached below the finest one
+                from . import backend
+                dev_id = (device_kwargs or {}).get("device_id", 0)
+                finer = self.sys.dev
+                for k in range(1, len(self._levels)):
+                    coarse = backend.DeviceSolver(self._levels[k][0], device_id=dev_id, shared_device=1)
+                    finer.attach_coarse_level(coarse, self._levels[k - 1][2], theta=ml_theta, sweeps=ml_sweeps)
+                    finer = coarse
         self.solver_parameters = solver_parameters or SOLVER_PARAMETERS
         self.tot_num_steps = self.pp.tot_num_steps if num_steps is None else int(num_steps)
         nv = self.mesh.num_vertices

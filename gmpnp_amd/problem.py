@@ -113,6 +113,24 @@ def pore_problem(pp, mesh: Mesh, quad: Quadrature = None, refine: int = 0):
     return prob, bnd
 
 
+def pore_hierarchy(pp, mesh: Mesh, refine: int, quad: Quadrature = None):
+    """The nested problems of a uniformly refined pore mesh, FINEST FIRST: [(problem, boundaries, parents), ...] with
+    ``parents`` (nv, 2) = the vertices of the next-coarser mesh each vertex interpolates from (None on the coarsest, the
+    reference mesh itself).  What the multilevel term of the preconditioner is built from (DeviceSolver.attach_coarse_level)."""
+    bnd = mark_pore_boundaries(mesh, pp.aspect_pore, pore_wall_tolerance(pp.L, pp.R))
+    levels = [(mesh, bnd)]
+    for _ in range(refine):
+        from .mesh import refine_pore
+        levels.append(refine_pore(*levels[-1]))
+    out = []
+    for m, b in levels[::-1]:
+        dofs, vals = pore_dirichlet(pp, b)
+        prob = Problem(coords=m.coords, cells=m.cells, model=pp.model, quad=quad, wall_facets=b.ds_facets[2], exit_facets=b.ds_facets[3],
+                       bc_dofs=dofs, bc_vals=vals)
+        out.append((prob, b, getattr(m, "parents", None)))
+    return out
+
+
 def edl_problem(ep, mesh: Mesh, quad: Quadrature = None):
     """Problem for the 1D EDL (reference 1D:237-254,350-355): all 7 fields pinned to
     (1,..,1,0) at x=1; p = voltage_multiplier at x=0; point fluxes at the x=0 vertex."""

@@ -329,6 +329,19 @@ int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* opts,
 int gmpnp_group_selftest(gmpnp_group* g, double* max_error);
 int gmpnp_group_assign_previous(gmpnp_group* g);
 
+/* Geometric multilevel term of the preconditioner on uniformly refined meshes (no reference counterpart: the reference solves
+ * with MUMPS, 3D:792; this keeps the iteration count of the Krylov stand-in from growing with the refinement level).
+ * `coarse` is an ordinary handle of the PARENT mesh of `fine`'s mesh (same model; its Dirichlet set decides its identity rows);
+ * parents[2 v + {0, 1}] = the two coarse vertices (coarse FILE order) fine vertex v (fine file order) interpolates from, both the
+ * same vertex when v is a copy of it (red refinement: every fine vertex is one or the other).  From then on every preconditioner
+ * set-up of `fine` injects the state into `coarse`, assembles the Jacobian there and sets up the coarse handle's own two-level
+ * preconditioner M_c^-1, and M^-1 of `fine` gains  theta * P S_c P^T  (additive), S_c = `sweeps` Richardson sweeps x <- x +
+ * PRE_c (r - J_c x) from x = 0 with PRE_c = M_c^-1 + [the same term for a level attached below `coarse`] — sweeps = 1 is purely
+ * additive, every further sweep costs one SpMV with J_c (1/8 of a fine one) (csrc/gmpnp_multilevel.h).
+ * Chains: attach level 2 to level 1, then level 1 to level 0.  `coarse` must outlive `fine` and must not be driven by the caller
+ * any more.  BiCGStab then runs in the materialised vector form.  3D, unpartitioned handles on one device. */
+int gmpnp_attach_coarse_level(gmpnp_solver* fine, gmpnp_solver* coarse, const int32_t* parents, double theta, int32_t sweeps);
+
 /* Benchmark hooks: time `launches` back-to-back launches of one kernel on the handle's stream with HIP
  * events; kernel: 0 = plain Jacobian SpMV, 1 = element kernel (F+J), 2 = Jacobian gather, 3 = residual gather,
  * 4/5 = fused BiCGStab half-iterations A/B, 6/7 = their scalar+coarse kernels, 8 = one-wave copy, 9-11 = streaming

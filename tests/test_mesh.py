@@ -114,3 +114,29 @@ def test_uniform_refinement_conserves_geometry_and_markers():
     m1 = read_dolfin_xml(resolve_mesh_path(UTIL, "1D_variable_1um_mesh_1090.xml.gz"))
     f1, _ = refine_uniform(m1)
     assert f1.num_cells == 2 * m1.num_cells and abs(f1.cell_volumes().sum() - 1.0) < 1e-13
+
+
+def test_refinement_records_the_nested_space_table():
+    """refine_uniform leaves, on the mesh it returns, the two parent vertices every vertex interpolates from: what the multilevel
+    term of the preconditioner is built from (gmpnp_attach_coarse_level); pore_hierarchy lists the levels finest first."""
+    import numpy as np
+    from gmpnp_amd.mesh import read_dolfin_xml, refine_uniform, resolve_mesh_path
+    from gmpnp_amd.params import pore_parameters, utilities_dir
+    from gmpnp_amd.problem import pore_hierarchy
+    pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
+    mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
+    fine, _ = refine_uniform(mesh)
+    par = fine.parents
+    nv = mesh.num_vertices
+    assert par.shape == (fine.num_vertices, 2) and np.array_equal(par[:nv, 0], np.arange(nv)) and np.array_equal(par[:nv, 0], par[:nv, 1])
+    assert (par[nv:, 0] != par[nv:, 1]).all()
+    assert np.abs(0.5 * (mesh.coords[par[:, 0]] + mesh.coords[par[:, 1]]) - fine.coords).max() == 0.0
+    lv = pore_hierarchy(pp, mesh, 2)
+    assert [p.coords.shape[0] for p, _, _ in lv] == [89305, 12109, 1767] and lv[2][2] is None
+    for k in (0, 1):   # P1 interpolation of a linear function is exact, and Dirichlet vertices of a coarse level stay Dirichlet on the finer one
+        pf, pc, par = lv[k][0], lv[k + 1][0], lv[k][2]
+        f = pc.coords @ np.array([0.3, -1.1, 2.0]) + 0.7
+        assert np.abs(0.5 * (f[par[:, 0]] + f[par[:, 1]]) - (pf.coords @ np.array([0.3, -1.1, 2.0]) + 0.7)).max() < 1e-13
+        copies = np.nonzero(par[:, 0] == par[:, 1])[0]
+        bc_f, bc_c = set(pf.bc_dofs.tolist()), set(pc.bc_dofs.tolist())
+        assert all(((int(v) * 9 + fld) in bc_f) for v in copies[:200] for fld in range(9) if (int(par[v, 0]) * 9 + fld) in bc_c)
