@@ -486,12 +486,20 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry):
         alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
         mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(4, 200)
         launches = dev.krylov_launches_per_iteration
+        ml_note = None
+        if a.multilevel and a.refine > 0:
+            # the live event brackets span whole half-iterations, i.e. the ~35 small launches of the multilevel term as well; the
+            # roofline line is about the streaming kernel, so it is timed by itself here (back-to-back launches, HIP events)
+            ml_note = "live half-iteration incl. the multilevel launches: %.1f us; the tile kernels alone (k_bicg_a_mat / k_bicg_b_mat, back-to-back): see mean_launch_us" % mean_us
+            mean_us = 0.5 * (dev.time_kernel(14, 50) + dev.time_kernel(15, 50))
         if launches == 2:
             kernel_name = ("k_half_a / k_half_b (one launch per BiCGStab half-iteration: the coarse workgroups ride in front of "
                            "the tile workgroups = SELL node-block SpMV + vector updates, fp64; the launch duration includes "
                            "the in-launch wait for the coarse result, which the 4-launch form spends in a separate launch)")
         else:
             kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
+        if a.multilevel and a.refine > 0:
+            kernel_name = "k_bicg_a_mat / k_bicg_b_mat (tile kernels of the materialised vector form: SELL node-block SpMV staging one vector, fp64)"
         achieved = alg_bytes / (mean_us * 1e-6) / 1e9
         # what an EMPTY start/stop event pair measures on this stream: each timed burst carries that much ONCE (a burst is 2 x
         # ~20 launches), reported for information
@@ -530,7 +538,7 @@ def make_output(a, run, dev, prof, nv, world, dt, its, kry):
                          "empty_event_pair_us": ev_overhead,   # information only: `achieved` uses the raw event time (conservative)
                          "timing": "one HIP event pair around the first burst of every Nth solve (back-to-back live half-iterations); mean = elapsed / half-iterations, launch gaps included",
                          "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
-                         "launches_per_krylov_iteration": launches},
+                         "launches_per_krylov_iteration": launches, "multilevel_note": ml_note},
         }
         if world == 1:
             out["scaling_note"] = "N = 1: one problem on one GPU; the field says weak because the contract has two values (at N > 1: strong = ONE problem partitioned, replicas = weak)"
