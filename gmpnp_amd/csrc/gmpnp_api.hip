@@ -158,6 +158,7 @@ struct gmpnp_solver {
   gmpnp_solver* ml_coarse = nullptr; double ml_theta = 1.0; bool ml_is_coarse = false;
   int ml_sweeps = 2;   // as the COARSEST level: smoothing steps per application (an intermediate level runs a V(1,1) cycle)
   double ml_omega = 0.7;   // damping of the smoothing steps
+  int ml_mid_jacobi = 1;   // intermediate levels smooth with node-block Jacobi alone (the slab coarse space stays with the coarsest level)
   DevBuf<int32_t> ml_par, ml_child_ptr, ml_child, ml_copy;
   DevBuf<double> ml_r, ml_w, ml_z;
 
@@ -315,7 +316,7 @@ int residual(gmpnp_solver* s, bool want_j, double* norm, int* flags) {
 template <int NF>
 void launch_coarse_chain(gmpnp_solver* s, const Ctx& c, hipStream_t st) {
   hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, st, c);
-  hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, st, c);
+  hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * s->c.coarse_chunks), dim3(kVecBlock), 0, st, c);
   const int n = s->ncoarse;
   hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, st, c);
   hipLaunchKernelGGL((k_coarse_invert<NF>), dim3(1), dim3(512), coarse_lds_bytes(n, NF), st, c);
@@ -378,6 +379,10 @@ int ml_level_apply(gmpnp_solver* top, gmpnp_solver* L) {
   const int n = (int)L->ndof;
   const dim3 vg(grid_for(n, 256));
   auto smooth = [&](const double* src, double scale_dst) -> int {   // ml_w = scale_dst * ml_w + omega * M_L^-1 src
+    if (L->ml_coarse && L->ml_mid_jacobi) {   // intermediate level: damped node-block Jacobi alone, one launch
+      hipLaunchKernelGGL((k_ml_jacobi<NF>), vg, dim3(256), 0, st, (const double*)L->c.Dinv, src, L->ml_w.p, scale_dst, L->ml_omega, n);
+      return GMPNP_OK;
+    }
     L->stream = st;
     const int rc = apply_minv<NF>(L, GMPNP_LINEAR_BICGSTAB_TWOLEVEL, src, L->ml_w.p, scale_dst, L->ml_omega, nullptr);
     L->stream = keep;
@@ -1216,7 +1221,10 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
   HIP_TRY(s->Dinv.alloc((size_t)nv * nf * nf));
   HIP_TRY(s->agg.upload(t.agg)); HIP_TRY(s->agg_start.upload(t.agg_start)); HIP_TRY(s->row_aggs.upload(t.row_aggs));
   HIP_TRY(s->AP.alloc((size_t)ndof * kMaxRowAggs * nf));
-  HIP_TRY(s->AcPart.alloc((size_t)kCoarseChunks * s->ncoarse * s->ncoarse));
+  // a few dozen nodes per chunk: 32 chunks per aggregate on the reference meshes, up to 1024 on refined ones (one workgroup each;
+  // with the fixed 32 a twice-refined mesh spent 1.9 ms here, 770 nodes in a serial loop per thread)
+  s->c.coarse_chunks = std::min(1024, std::max(kCoarseChunks, nv / std::max(1, s->t.nagg) / 24));
+  HIP_TRY(s->AcPart.alloc((size_t)s->c.coarse_chunks * s->ncoarse * s->ncoarse));
   HIP_TRY(s->Ac.alloc((size_t)s->ncoarse * s->ncoarse)); HIP_TRY(s->Aci.alloc((size_t)s->ncoarse * s->ncoarse));
   HIP_TRY(s->Aci2.alloc((size_t)s->ncoarse * s->ncoarse));
   const gmpnp_options_t& po = s->opts;

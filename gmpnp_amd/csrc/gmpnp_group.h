@@ -278,7 +278,7 @@ int group_setup(gmpnp_group* g, int mode, bool rebuild_coarse = true) {
     for (gmpnp_solver* s : g->dom) {
       const int n = s->ncoarse;
       hipLaunchKernelGGL((k_coarse_rows<NF>), dim3(s->t.nslices), dim3(64), 0, s->stream, s->c);
-      hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * kCoarseChunks), dim3(kVecBlock), 0, s->stream, s->c);
+      hipLaunchKernelGGL((k_coarse_sum<NF>), dim3(s->t.nagg * s->c.coarse_chunks), dim3(kVecBlock), 0, s->stream, s->c);
       hipLaunchKernelGGL(k_coarse_reduce, dim3(grid_for(n * n, kVecBlock)), dim3(kVecBlock), 0, s->stream, s->c);
       hipLaunchKernelGGL(k_zero_foreign_rows, dim3(grid_for(n * n, 256)), dim3(256), 0, s->stream, s->Ac.p, n, s->t.own_agg0 * NF, s->t.own_agg1 * NF);
     }

@@ -15,7 +15,7 @@ constexpr int kWave = 64;           // CDNA wavefront
 constexpr int kVecBlock = 256;      // threads per workgroup of the vector kernels
 constexpr int kMaxRowAggs = 4;      // distinct coarse aggregates a block row may touch
 constexpr int kMaxCoarse = 140;     // coarse dimension limit: n^2 doubles must fit the 160 KiB LDS
-constexpr int kCoarseChunks = 32;   // node chunks per aggregate in the Galerkin-product reduction
+constexpr int kCoarseChunks = 32;   // node chunks per aggregate in the Galerkin-product reduction: the minimum (Ctx::coarse_chunks grows with the mesh)
 #ifndef GMPNP_SLICES_PER_TILE
 #define GMPNP_SLICES_PER_TILE 1
 #endif
@@ -143,7 +143,8 @@ struct Ctx {
   const int32_t* agg_start;     // [nagg+1] node ranges
   const int32_t* row_aggs;      // [nv][kMaxRowAggs]
   double* AP;                   // [ndof][kMaxRowAggs][NF]
-  double* AcPart;               // [kCoarseChunks][ncoarse][ncoarse] partial sums of Ac
+  double* AcPart;               // [coarse_chunks][ncoarse][ncoarse] partial sums of Ac
+  int32_t coarse_chunks;        // node chunks per aggregate in k_coarse_sum: 32 ... 1024, about 24 nodes each
   double* Ac;                   // [ncoarse][ncoarse]
   double* Aci;                  // inverse, row major
   // Krylov vectors (right-scaled system A Dinv (I + P Aci P^T) y = b)

@@ -671,9 +671,9 @@ __global__ __launch_bounds__(64) void k_coarse_rows(const Ctx c) {
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_coarse_sum(const Ctx c) {
   // workgroup (g, chunk): partial sums over one chunk of the nodes of aggregate g
-  const int g = blockIdx.x / kCoarseChunks, ch = blockIdx.x - g * kCoarseChunks, n = c.ncoarse;
+  const int nch = c.coarse_chunks, g = blockIdx.x / nch, ch = blockIdx.x - g * nch, n = c.ncoarse;
   const int a0 = c.agg_start[g], len = c.agg_start[g + 1] - a0;
-  const int I0 = a0 + (int)((int64_t)len * ch / kCoarseChunks), I1 = a0 + (int)((int64_t)len * (ch + 1) / kCoarseChunks);
+  const int I0 = a0 + (int)((int64_t)len * ch / nch), I1 = a0 + (int)((int64_t)len * (ch + 1) / nch);
   double* out = c.AcPart + ((size_t)ch * n + (size_t)g * NF) * n;
   for (int idx = threadIdx.x; idx < NF * n; idx += kVecBlock) {
     const int i = idx / n, col = idx - i * n, h = col / NF, j = col - h * NF;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kVecBlock) void k_coarse_reduce(const Ctx c) {
   const int n2 = c.ncoarse * c.ncoarse, q = blockIdx.x * kVecBlock + threadIdx.x;
   if (q >= n2) return;
   double s = 0.0;
-  for (int ch = 0; ch < kCoarseChunks; ++ch) s += c.AcPart[(size_t)ch * n2 + q];
+  for (int ch = 0; ch < c.coarse_chunks; ++ch) s += c.AcPart[(size_t)ch * n2 + q];
   c.Ac[q] = s;
 }
 
