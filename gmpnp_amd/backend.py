@@ -72,7 +72,7 @@ class COptions(ctypes.Structure):
                 ("krylov_batch", c_int32), ("profile_every", c_int32), ("launch_form", c_int32),
                 ("warm_start", c_int32), ("coarse_refresh", c_int32), ("progress_by_copy", c_int32),
                 ("burst_iterations", c_int32), ("phase_timing", c_int32), ("no_direct_fallback", c_int32),
-                ("warm_in_stream", c_int32), ("vector_form", c_int32), ("strict_steric", c_int32), ("reserved_", c_int32 * 1), ("band_lu_max_gb", c_double)]
+                ("warm_in_stream", c_int32), ("vector_form", c_int32), ("strict_steric", c_int32), ("element_stores", c_int32), ("band_lu_max_gb", c_double)]
 
 
 class CPartition(ctypes.Structure):
@@ -267,7 +267,7 @@ class DeviceSolver:
     def __init__(self, problem: Problem, device_id: int = 0, n_aggregates: int = 0, krylov_batch: int = 0,
                  profile_every: int = 0, perm: np.ndarray = None, lib=None, partition: dict = None, **options):
         """``options``: further fields of ``gmpnp_options_t`` by name (shared_device, launch_form, warm_start,
-        coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream, vector_form, strict_steric,
+        coarse_refresh, progress_by_copy, burst_iterations, phase_timing, no_direct_fallback, warm_in_stream, vector_form, strict_steric, element_stores,
         band_lu_max_gb); all default to 0."""
         self.lib = lib or load_library()
         self.problem = problem

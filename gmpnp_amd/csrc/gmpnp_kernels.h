@@ -102,10 +102,38 @@ __device__ inline void sum_partials(const double* __restrict__ part, int n, int 
 // ---------------------------------------------------------------------------------------------
 // Element kernel: one lane per cell.
 // ---------------------------------------------------------------------------------------------
-template <int DIM, int NF, bool WANT_J>
-__global__ __launch_bounds__(64) void k_element(const Ctx c) {
+// STAGED (3D meshes): a lane's record words are collected in LDS piece by piece (at most 64 words at a time) and the WAVE writes
+// them out record by record, up to 512 contiguous bytes per store instruction.  With one lane per cell and direct stores every
+// store instruction touches 64 records 1.6 KB apart, and a wave keeps 64 x 1.9 KB of half-written records open for its whole
+// life — once those no longer fit the L2s (1,024 resident waves x 124 KB) the records reach HBM as partial lines.  Measured
+// (tools/assembly_at_scale.py): twice-refined L_50_R_5, 2.1 GB of records: 2.00 -> 1.18 ms (1.07 -> 1.82 TB/s); L_50_R_5 itself:
+// 40.5 -> 36.6 us.  Bit-identical results (tests/test_gpu_parity.py::test_staged_element_stores_give_the_same_bits).  More waves
+// per SIMD do not help (the kernel needs all 512 registers: 2 waves spill, direct form 2x slower, staged form unchanged).
+constexpr int kStageWords = 64, kStagePitch = 65;   // odd pitch: lane r writes word w at r*65 + w without bank conflicts
+template <bool STAGED>
+__device__ __forceinline__ void elem_put(double* __restrict__ direct, double* __restrict__ stage, int idx_in_piece, int word, double v) {
+  if (STAGED) stage[(threadIdx.x & 63) * kStagePitch + idx_in_piece] = v; else direct[word] = v;
+}
+// piece [base, base + len) of the records of cells e0 .. e0 + 63 (array `arr`, `stride` doubles per record): out of LDS, coalesced
+__device__ __forceinline__ void elem_flush(double* __restrict__ arr, size_t stride, int base, int len, const double* __restrict__ stage, int e0, int nc) {
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  if (lane < len) {
+    const int nrec = min(64, nc - e0);
+#pragma unroll 8
+    for (int r = 0; r < nrec; ++r) arr[(size_t)(e0 + r) * stride + base + lane] = stage[r * kStagePitch + lane];
+  }
+  __syncthreads();
+}
+#ifndef GMPNP_ELEMENT_WAVES
+#define GMPNP_ELEMENT_WAVES 1
+#endif
+template <int DIM, int NF, bool WANT_J, bool STAGED = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMPNP_ELEMENT_WAVES, GMPNP_ELEMENT_WAVES))) void k_element(const Ctx c) {
   using L = Lay<DIM, NF>;
   constexpr int NS = L::NS, NN = L::NN;
+  static_assert(!STAGED || DIM == 3, "staged record stores: 3D meshes");
+  __shared__ double stage[STAGED ? 64 * kStagePitch : 1];
   // Coefficient and quadrature tables go to LDS first: read through the global pointers they would be re-fetched with
   // a vector load (and a full wait) at every use, because the element stores below may alias them.
   __shared__ gmpnp_model_t m;
@@ -120,8 +148,9 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
     for (int w = threadIdx.x; w < (int)(sizeof(gmpnp_quadrature_t) / 4); w += blockDim.x) lq[w] = gq[w];
   }
   __syncthreads();
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= c.nc) return;
+  const int e0 = blockIdx.x * blockDim.x;
+  if (!STAGED && e0 + (int)threadIdx.x >= c.nc) return;
+  const int e = min(e0 + (int)threadIdx.x, c.nc - 1);   // STAGED: every lane stays for the copy-out (surplus lanes redo the last cell; never stored)
 
   int nd[NN];
   double X[NN][DIM], U[NN][NF];
@@ -271,13 +300,19 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
       mono[t][a] = vol * L::KAPPA * (Xs * Ys + xs[a] * Ys + Xs * ys[a] + D + 2.0 * xs[a] * ys[a]);
     if constexpr (WANT_J) {  // derivative tables of the monomial: the Jacobian gather reads two numbers per term
       double* dt = c.EJ + (size_t)e * L::EJ_STRIDE + L::O_D + t * 2 * NN * NN;
+      const int sp = (t & 1) * 2 * NN * NN;   // STAGED: two terms (2 x 32 words) share a piece
 #pragma unroll
       for (int a = 0; a < NN; ++a)
 #pragma unroll
         for (int b = 0; b < NN; ++b) {
-          dt[a * NN + b] = vol * L::KAPPA * (Ys + ys[a] + ys[b] + (a == b ? Ys + 2.0 * ys[a] : 0.0));            // d/d u_{bj,b}
-          dt[NN * NN + a * NN + b] = vol * L::KAPPA * (Xs + xs[a] + xs[b] + (a == b ? Xs + 2.0 * xs[a] : 0.0));  // d/d u_{bk,b}
+          elem_put<STAGED>(dt, stage, sp + a * NN + b, a * NN + b, vol * L::KAPPA * (Ys + ys[a] + ys[b] + (a == b ? Ys + 2.0 * ys[a] : 0.0)));            // d/d u_{bj,b}
+          elem_put<STAGED>(dt, stage, sp + NN * NN + a * NN + b, NN * NN + a * NN + b, vol * L::KAPPA * (Xs + xs[a] + xs[b] + (a == b ? Xs + 2.0 * xs[a] : 0.0)));  // d/d u_{bk,b}
         }
+      if constexpr (STAGED) {
+        static_assert(!STAGED || 4 * NN * NN <= kStageWords, "two terms per piece");
+        if ((t & 1) || t + 1 == m.n_bilinear)
+          elem_flush(c.EJ, L::EJ_STRIDE, L::O_D + (t & ~1) * 2 * NN * NN, ((t & 1) ? 4 : 2) * NN * NN, stage, e0, c.nc);
+      }
     }
   }
 #pragma unroll
@@ -301,10 +336,14 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
       for (int j = 0; j < NS; ++j) f += m.rc1[i][j] * (vol * L::MDEN * (usum[j] + U[a][j]));
       for (int t = 0; t < m.n_bilinear; ++t) f += m.rc2[i][t] * mono[t][a];
       f += If[i] * Gg[a];
-      ef[a * NF + i] = f;
+      elem_put<STAGED>(ef, stage, a * NF + i, a * NF + i, f);
       fp += m.qzb[i] * (vol * L::MDEN * (usum[i] + U[a][i]));
     }
-    ef[a * NF + NS] = fp;
+    elem_put<STAGED>(ef, stage, a * NF + NS, a * NF + NS, fp);
+  }
+  if constexpr (STAGED) {
+    static_assert(!STAGED || L::EF_STRIDE <= kStageWords, "the residual rows are one piece");
+    elem_flush(c.EF, L::EF_STRIDE, 0, L::EF_STRIDE, stage, e0, c.nc);
   }
   // ---- SUPG stabilisation of the PNP model (reference 1D:687-714; 1D meshes only) -----------------------------------
   //   F_stab = - sum_i rho_i z_i [ (u_i - u_i^n)/(dt L_D) + z_i grad(w_i).grad(p) + R_i ] grad(p).grad(v_i) dx
@@ -410,20 +449,32 @@ __global__ __launch_bounds__(64) void k_element(const Ctx c) {
   }
   if constexpr (WANT_J) {
     double* ej = c.EJ + (size_t)e * L::EJ_STRIDE;
-    ej[L::O_VOL] = vol;
+    // two pieces: [0, O_B) = volume, gradients, means, eps, int u beta; [O_B, O_D) = int beta phi, int u beta^2 phi
+    elem_put<STAGED>(ej, stage, L::O_VOL, L::O_VOL, vol);
 #pragma unroll
     for (int a = 0; a < NN; ++a) {
 #pragma unroll
-      for (int b = 0; b < NN; ++b) ej[L::O_GG + a * NN + b] = gg[a][b];
-      ej[L::O_GP + a] = gp[a]; ej[L::O_GG_A + a] = Gg[a]; ej[L::O_B + a] = Bq[a];
+      for (int b = 0; b < NN; ++b) elem_put<STAGED>(ej, stage, L::O_GG + a * NN + b, L::O_GG + a * NN + b, gg[a][b]);
+      elem_put<STAGED>(ej, stage, L::O_GP + a, L::O_GP + a, gp[a]);
+      elem_put<STAGED>(ej, stage, L::O_GG_A + a, L::O_GG_A + a, Gg[a]);
     }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      ej[L::O_UBAR + j] = ubar[j]; ej[L::O_IJ + j] = Ij[j];
-#pragma unroll
-      for (int b = 0; b < NN; ++b) ej[L::O_C + j * NN + b] = Cq[j][b];
+      elem_put<STAGED>(ej, stage, L::O_UBAR + j, L::O_UBAR + j, ubar[j]);
+      elem_put<STAGED>(ej, stage, L::O_IJ + j, L::O_IJ + j, Ij[j]);
     }
-    ej[L::O_EPS] = epsbar;
+    elem_put<STAGED>(ej, stage, L::O_EPS, L::O_EPS, epsbar);
+    if constexpr (STAGED) {
+      static_assert(!STAGED || (L::O_B <= kStageWords && L::O_D - L::O_B <= kStageWords), "the record head is two pieces");
+      elem_flush(c.EJ, L::EJ_STRIDE, 0, L::O_B, stage, e0, c.nc);
+    }
+#pragma unroll
+    for (int a = 0; a < NN; ++a) elem_put<STAGED>(ej, stage, a, L::O_B + a, Bq[a]);
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+      for (int b = 0; b < NN; ++b) elem_put<STAGED>(ej, stage, (L::O_C - L::O_B) + j * NN + b, L::O_C + j * NN + b, Cq[j][b]);
+    if constexpr (STAGED) elem_flush(c.EJ, L::EJ_STRIDE, L::O_B, L::O_D - L::O_B, stage, e0, c.nc);
   }
 }
 

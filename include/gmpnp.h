@@ -172,7 +172,9 @@ typedef struct {
   int32_t strict_steric;  /* 1 = an iterate with 1 - sum_j a_j u_j <= 0 at a quadrature point ends the solve with GMPNP_ERR_NUMERIC
                              (rounds 1-2).  0 (default) = the reference's behaviour: no such test; an iterate that overshoots
                              and comes back converges, one that does not ends as NaN / not converged */
-  int32_t reserved_[1];   /* zero */
+  int32_t element_stores; /* how the element kernel writes its per-cell records: 0 = automatic (3D: staged through LDS and written
+                             record by record, up to 512 contiguous bytes per store instruction; 1D: direct), 1 = direct stores of
+                             one lane per cell (every store instruction touches 64 records 1.6 KB apart), 2 = staged */
   double band_lu_max_gb;  /* largest band storage the direct solver may allocate; 0 = 48 */
 } gmpnp_options_t;
 

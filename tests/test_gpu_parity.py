@@ -76,6 +76,25 @@ def test_assembly_as_published_variant(pore10, gpu_lib):
     assert relerr(Fo, Fi) > 1e-6  # the flux terms do matter
 
 
+def test_staged_element_stores_give_the_same_bits(pore10, gpu_lib):
+    """The element kernel's two ways of writing its per-cell records (direct stores of one lane per cell; staged through LDS and
+    written record by record, the form large meshes take) leave bit-identical residuals and Jacobians — on a mesh whose cell count
+    is not a multiple of 64 (the last wave is ragged)."""
+    prob = pore10[2]
+    assert prob.cells.shape[0] % 64 != 0
+    u, un = random_state(prob.coords.shape[0], 8, seed=5)
+    out = []
+    for mode in (1, 2):
+        with gpu_lib.DeviceSolver(prob, element_stores=mode) as dev:
+            dev.set_state(u, un)
+            F, _ = dev.assemble(True)
+            out.append((F, dev.jacobian_csr()))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].data, out[1][1].data) and np.array_equal(out[0][1].indices, out[1][1].indices)
+    Fo, Ao = O.assemble(prob, u, un)
+    assert relerr(out[1][0], Fo) < 1e-12 and frob_rel(out[1][1], Ao) < 1e-12
+
+
 def test_steric_excursion_is_information_by_default_and_fatal_on_request(pore10, gpu_lib):
     """UFL/FFC evaluate u_i / (1 - S) as it stands (3D:534-750): a state with 1 - S <= 0 at quadrature points assembles like any
     other (negative quotients) — and so it does here, matching the oracle; `strict_steric` brings back the rounds-1-2 error."""
