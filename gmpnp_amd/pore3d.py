@@ -3,7 +3,8 @@ reference 3D/MPNP_CO2ER_pore.py (``solveEDL`` 3D:96-1085, CLI 3D:1088-1253; SURV
 
 Differences, all explicit: input/output roots come from ``$GMPNP_UTILITIES`` / ``$GMPNP_OUT`` instead of the
 author's hard-coded macOS paths (SURVEY Q10); ``--num_steps`` (not in the reference) shortens the 1000-step loop;
-``--as_published`` drops the ds(2)/ds(3) flux terms that the published script never adds to F."""
+``--as_published`` drops the ds(2)/ds(3) flux terms that the published script never adds to F; ``--refine N`` /
+``--multilevel`` run on the N times uniformly refined mesh (with the multilevel term of the preconditioner)."""
 from __future__ import annotations
 
 import argparse
@@ -179,9 +180,11 @@ class PoreRun:
 def solveEDL(concentration_elec=1.0, voltage_multiplier=-1.0, H2_FE=0.05, current_rough=3000.0, L=100.0e-9,
              cation="K", R=5.0e-9, press_gas=1.0, pore_geom_multiplier=1.0, porosity_eff=0.5, tortuosity_eff=1.5,
              constrictivity_eff=0.9, params_file="parameters_pore", y_CO2=0.95, electrolyte_flow_geom_multiplier=1.0,
-             roughness_factor=150.0, num_steps=None, as_published=False, verbose=True):
-    """Same keyword surface as the reference's ``solveEDL`` (3D:96-113); returns the output directory."""
-    run = PoreRun(num_steps=num_steps, as_published=as_published, concentration_elec=concentration_elec,
+             roughness_factor=150.0, num_steps=None, as_published=False, verbose=True, refine=0, multilevel=False):
+    """Same keyword surface as the reference's ``solveEDL`` (3D:96-113); returns the output directory.  Additions:
+    ``num_steps``, ``as_published``, ``refine`` (uniform refinements of the mesh file), ``multilevel`` (with ``refine`` > 0: the
+    geometric multilevel term of the preconditioner)."""
+    run = PoreRun(num_steps=num_steps, as_published=as_published, refine=refine, multilevel=multilevel, concentration_elec=concentration_elec,
                   voltage_multiplier=voltage_multiplier, H2_FE=H2_FE, current_rough=current_rough, L=L, cation=cation,
                   R=R, press_gas=press_gas, pore_geom_multiplier=pore_geom_multiplier, porosity_eff=porosity_eff,
                   tortuosity_eff=tortuosity_eff, constrictivity_eff=constrictivity_eff, params_file=params_file,
@@ -210,6 +213,8 @@ def build_parser():
     # additions (not in the reference)
     p.add_argument("--num_steps", required=False, default=None, type=int, help="run only the first N time steps")
     p.add_argument("--as_published", action="store_true", help="drop the ds(2)/ds(3) flux terms (SURVEY Q1)")
+    p.add_argument("--refine", required=False, default=0, type=int, help="uniform (red) refinements of the mesh file, markers inherited")
+    p.add_argument("--multilevel", action="store_true", help="with --refine > 0: geometric multilevel term of the preconditioner over the nested meshes")
     return p
 
 
@@ -221,7 +226,8 @@ def main(argv=None):
                     constrictivity_eff=a.constrictivity_eff, params_file=a.params_file, y_CO2=a.y_CO2,
                     pore_geom_multiplier=a.pore_geom_multiplier,
                     electrolyte_flow_geom_multiplier=a.electrolyte_flow_geom_multiplier,
-                    roughness_factor=a.roughness_factor, num_steps=a.num_steps, as_published=a.as_published)
+                    roughness_factor=a.roughness_factor, num_steps=a.num_steps, as_published=a.as_published, refine=a.refine,
+                    multilevel=a.multilevel)
 
 
 if __name__ == "__main__":
