@@ -37,7 +37,8 @@ def ramp_value(target, n, ramp_steps, start=-1.0):
     return float(start + (target - start) * min(n, ramp_steps) / ramp_steps)
 
 
-def run_job(radius_nm, voltage, num_steps, concentration_elec=0.5, device_id=0, write=False, as_published=False, ramp_steps=0):
+def run_job(radius_nm, voltage, num_steps, concentration_elec=0.5, device_id=0, write=False, as_published=False, ramp_steps=0,
+            one_stream=False):
     """One pore run of ``num_steps`` time steps; returns a small summary dict (never raises for a diverged Newton).
 
     ``ramp_steps`` > 0 is a continuation the reference does not have: the wall potential Dirichlet value (bc3 of
@@ -52,7 +53,9 @@ def run_job(radius_nm, voltage, num_steps, concentration_elec=0.5, device_id=0, 
     try:
         run = PoreRun(num_steps=num_steps, concentration_elec=concentration_elec, L=50e-9, R=radius_nm * 1e-9,
                       voltage_multiplier=ramp_value(voltage, 0, ramp_steps), as_published=as_published,
-                      device_kwargs={"device_id": device_id})
+                      # several runs in flight on one GPU: every handle keeps to ONE stream (coarse rebuild and warm-start test in
+                      # the main stream): with side streams K handles are 2K streams on the process's four hardware queues
+                      device_kwargs=dict({"device_id": device_id}, **({"coarse_refresh": 3, "warm_in_stream": 1} if one_stream else {})))
         out.update(n_vertices=run.mesh.num_vertices, n_dofs=run.problem.ndof)
         for n in range(num_steps):
             run.step(verbose=False)
@@ -86,7 +89,7 @@ def main(argv=None):
     p.add_argument("--ramp_steps", type=int, default=0,
                    help="move the wall potential from -1 to the target over this many time steps (continuation; 0 = the "
                         "reference's behaviour, the target applies from step 0)")
-    p.add_argument("--jobs_per_gpu", type=int, default=1, help="independent runs kept in flight on each GPU (separate streams)")
+    p.add_argument("--jobs_per_gpu", type=int, default=1, help="independent runs kept in flight on each GPU (separate streams; 3 gives 1.56x the throughput of 1)")
     p.add_argument("--write", action="store_true", help="write the reference's output files of every run under $GMPNP_OUT")
     p.add_argument("--backend", default=None, help="torch.distributed backend for the final gather (default: nccl)")
     a = p.parse_args(argv)
@@ -109,12 +112,14 @@ def main(argv=None):
     t0 = time.perf_counter()
     def one(job):
         return run_job(job[0], job[1], a.num_steps, a.concentration_elec, device_id=local, write=a.write,
-                       as_published=a.as_published, ramp_steps=a.ramp_steps)
+                       as_published=a.as_published, ramp_steps=a.ramp_steps, one_stream=a.jobs_per_gpu > 1)
 
     if a.jobs_per_gpu > 1:
         # A 3.7k-vertex problem is launch-latency bound: independent problems on separate HIP streams
-        # overlap on one GPU (two concurrent L_50_R_5 runs measured 1.74x the throughput of one).  One host thread
-        # per job; ctypes releases the GIL inside the library.
+        # overlap on one GPU.  Measured (tools/concurrent_runs_probe.py, profiles/r03/concurrent_runs*.json): 2 / 3 / 4 runs from
+        # threads of one process = 1.40 / 1.56 / 1.38 x the throughput of one (3 is the sweet spot: a launch needs 537 of the
+        # GPU's 768 workgroup slots, so launches of different problems overlap by their tails only).  One host thread per job;
+        # ctypes releases the GIL inside the library.
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=a.jobs_per_gpu) as pool:
             res = list(pool.map(one, mine))

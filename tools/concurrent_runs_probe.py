@@ -60,7 +60,10 @@ def measure(K, **device_kwargs):
 
 rows = []
 CASES = ((1, {}), (2, {}), (3, {}), (4, {}), (2, {"shared_device": 1}), (4, {"shared_device": 1}), (6, {"shared_device": 1}))
-if os.environ.get("PROBE_CASES"):   # e.g. "3,4,5,6" (default options) — with GPU_MAX_HW_QUEUES set by the caller
+if os.environ.get("PROBE_ONE_STREAM"):   # one stream per handle (coarse rebuild and warm-start test in the main stream), two-launch form kept
+    kw1 = {"coarse_refresh": 3, "warm_in_stream": 1}
+    CASES = ((1, {}), (1, kw1), (2, kw1), (3, kw1), (4, kw1), (5, kw1))
+elif os.environ.get("PROBE_CASES"):   # e.g. "3,4,5,6" (default options) — with GPU_MAX_HW_QUEUES set by the caller
     CASES = ((1, {}),) + tuple((int(k), {}) for k in os.environ["PROBE_CASES"].split(","))
 for K, kw in CASES:
     try:
