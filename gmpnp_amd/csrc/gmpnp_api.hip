@@ -426,8 +426,8 @@ int ml_correction(gmpnp_solver* s, const double* src) {
 template <int NF>
 int ml_stage(gmpnp_solver* s, const double* vec) {
   int rc = ml_correction<NF>(s, vec); if (rc) return rc;
-  hipLaunchKernelGGL((k_ml_stage<NF>), dim3(grid_for(s->ndof, 256)), dim3(256), 0, s->stream, s->c, (const double*)s->ml_coarse->ml_w.p, (const int32_t*)s->ml_par.p,
-                     vec, s->ml_z.p, s->ml_theta);
+  hipLaunchKernelGGL((k_ml_stage<NF>), dim3(grid_for(s->ndof, kMlStageNodes * NF)), dim3(kMlStageNodes * NF), 0, s->stream, s->c, (const double*)s->ml_coarse->ml_w.p,
+                     (const int32_t*)s->ml_par.p, vec, s->ml_z.p, s->ml_theta);
   return GMPNP_OK;
 }
 // Once per preconditioner set-up: the state goes one level down by injection, the coarser level assembles ITS Jacobian there
