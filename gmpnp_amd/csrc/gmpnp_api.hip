@@ -407,8 +407,10 @@ int ml_level_apply(gmpnp_solver* top, gmpnp_solver* L) {
                        (const int32_t*)L->ml_child.p, C->c.bcflag, C->ml_r.p, (int)C->ndof);
     rc = ml_level_apply<NF>(top, C); if (rc) return rc;
     hipLaunchKernelGGL((k_ml_prolong_add<NF>), vg, dim3(256), 0, st, (const double*)C->ml_w.p, (const int32_t*)L->ml_par.p, L->c.bcflag, L->ml_w.p, n);
+#ifndef GMPNP_ML_NO_POST   // (A/B builds only: V(1,0) on the intermediate levels)
     residual();
     rc = smooth(L->ks.p, 1.0); if (rc) return rc;
+#endif
   } else {
     for (int k = 1; k < L->ml_sweeps; ++k) { residual(); rc = smooth(L->ks.p, 1.0); if (rc) return rc; }
   }
