@@ -1145,8 +1145,8 @@ def test_partition_plans_are_refused_when_inconsistent(pore10, gpu_lib):
 def test_multilevel_term_changes_iteration_counts_not_results(gpu_lib):
     """The geometric multilevel term of the preconditioner (gmpnp_attach_coarse_level; once-refined L_10_R_5, two nested meshes):
     identical Newton counts, states to solver accuracy, less than half the BiCGStab iterations of the two-level scheme; the coarse
-    level is assembled by this library's own kernels at the injected state.  (Twice-refined L_50_R_5, 1.77 M dofs: 206 -> 26
-    iterations per solve, 188 -> 55 ms per Newton iteration, profiles/r03/multilevel_refine2.json.)"""
+    level is assembled by this library's own kernels at the injected state.  (L_50_R_5 refined twice / three times, 1.77 M / 13.7 M dofs:
+    206 -> 25 / 494 -> 29 iterations per solve, Newton iterations 3.8 x / 8.6 x faster, profiles/r03/multilevel_refine{2,3}.json.)"""
     from gmpnp_amd.pore3d import PoreRun
     out = {}
     for name, kw in (("two-level", {}), ("multilevel", {"multilevel": True})):
