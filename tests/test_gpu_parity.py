@@ -1173,6 +1173,27 @@ def _pore_case(L):
     return _pore(L, 5e-9)
 
 
+def test_refined_multilevel_run_through_the_driver_and_the_bench(tmp_path, monkeypatch, gpu_lib):
+    """`--refine 1 --multilevel` through the 3D driver's CLI (outputs on the refined mesh: 12,109 vertices) and through bench.py
+    (the line names the preconditioner and times the tile kernels by themselves for the roofline object)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    monkeypatch.setenv("GMPNP_OUT", str(tmp_path))
+    from gmpnp_amd import pore3d
+    out = pore3d.main(["--L=10e-9", "--R=5e-9", "--concentration_elec=0.5", "--num_steps=1", "--refine=1", "--multilevel"])
+    a = np.load(os.path.join(out, "arrays_unscaled.npz"))
+    assert a["p"].shape == (2, 12109) and a["field_values"].shape == (3 * 12109,) and np.isfinite(a["cat_grad"]).all()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mesh", "L_10_R_5", "--refine", "1", "--multilevel", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-edl50"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "multilevel" in line["config"]["preconditioner"] and line["config"]["n_vertices"] == 12109
+    assert line["roofline"]["multilevel_note"] and "k_bicg_a_mat" in line["roofline"]["kernel"] and 0.0 < line["roofline"]["frac"] < 1.0
+    assert line["roofline"]["launches_per_krylov_iteration"] == 4
+
+
 # ---- closed-form pins of the 3D forms (tests/closed_forms.py): the same four cases run with the oracle in tests/test_oracle_pins.py ----
 TIGHT = {"nonlinear_solver": "newton", "newton_solver": {"linear_solver": "mumps", "maximum_iterations": 50, "relative_tolerance": 1e-12,
                                                          "absolute_tolerance": 1e-10, "relaxation_parameter": 1.0}}
