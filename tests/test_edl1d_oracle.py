@@ -106,6 +106,22 @@ def test_newton_at_saturation_is_quadratic_only_with_one_rule():
     assert hist[("long double", 3)][28:].max() < 1e-2 * np.median(mixed[20:])   # round-off: 11 more mantissa bits lower it
 
 
+def test_trajectory_is_insensitive_to_the_arithmetic_with_one_rule():
+    """With J = dF the trajectory is a property of the discrete problem, not of the arithmetic: 60 solves of the V = -12.5 schedule in
+    double and in x87 extended precision (state carried in that precision) take the same Newton iterations and end 1e-10 apart —
+    the distance two double-precision implementations (this oracle, the GPU product, FEniCS) can be expected to keep."""
+    out = {}
+    for kind in ("double", "long double"):
+        s = edl1d.Setup(voltage_multiplier=-12.5, dry_run=False)
+        u, un = s.initial_state()
+        u, un, its, done, _ = edl1d.run(s, 60, u, un, kind=kind)
+        assert done == 60
+        out[kind] = (un, its.copy())
+    assert np.array_equal(out["double"][1], out["long double"][1])
+    a, b = out["double"][0], out["long double"][0]
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-10
+
+
 def test_agrees_with_the_numpy_oracle():
     import gmpnp_oracle as O
     from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
