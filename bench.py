@@ -486,74 +486,73 @@ def main():
 
 def make_output(a, run, dev, prof, nv, world, dt, its, kry):
     """Everything of the JSON line that does not depend on the partitioned phase."""
-    if True:
-        nb, nd = dev.n_blocks, dev.ndof
-        nf = dev.nf
-        alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
-        mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(4, 200)
-        launches = dev.krylov_launches_per_iteration
-        ml_note = None
-        if a.multilevel and a.refine > 0:
-            # the live event brackets span whole half-iterations, i.e. the ~35 small launches of the multilevel term as well; the
-            # roofline line is about the streaming kernel, so it is timed by itself here (back-to-back launches, HIP events)
-            ml_note = "live half-iteration incl. the multilevel launches: %.1f us; the tile kernels alone (k_bicg_a_mat / k_bicg_b_mat, back-to-back): see mean_launch_us" % mean_us
-            mean_us = 0.5 * (dev.time_kernel(14, 50) + dev.time_kernel(15, 50))
-        if launches == 2:
-            kernel_name = ("k_half_a / k_half_b (one launch per BiCGStab half-iteration: the coarse workgroups ride in front of "
-                           "the tile workgroups = SELL node-block SpMV + vector updates, fp64; the launch duration includes "
-                           "the in-launch wait for the coarse result, which the 4-launch form spends in a separate launch)")
+    nb, nd = dev.n_blocks, dev.ndof
+    nf = dev.nf
+    alg_bytes = (nf * nf * 8) * nb + 4 * nb + 4 * (nv + 1) + 16 * nd  # SURVEY §8d, one SpMV
+    mean_us = prof["mean_us"] if prof["sampled"] else dev.time_kernel(4, 200)
+    launches = dev.krylov_launches_per_iteration
+    ml_note = None
+    if a.multilevel and a.refine > 0:
+        # the live event brackets span whole half-iterations, i.e. the ~35 small launches of the multilevel term as well; the
+        # roofline line is about the streaming kernel, so it is timed by itself here (back-to-back launches, HIP events)
+        ml_note = "live half-iteration incl. the multilevel launches: %.1f us; the tile kernels alone (k_bicg_a_mat / k_bicg_b_mat, back-to-back): see mean_launch_us" % mean_us
+        mean_us = 0.5 * (dev.time_kernel(14, 50) + dev.time_kernel(15, 50))
+    if launches == 2:
+        kernel_name = ("k_half_a / k_half_b (one launch per BiCGStab half-iteration: the coarse workgroups ride in front of "
+                       "the tile workgroups = SELL node-block SpMV + vector updates, fp64; the launch duration includes "
+                       "the in-launch wait for the coarse result, which the 4-launch form spends in a separate launch)")
+    else:
+        kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
+    if a.multilevel and a.refine > 0:
+        kernel_name = "k_bicg_a_mat / k_bicg_b_mat (tile kernels of the materialised vector form: SELL node-block SpMV staging one vector, fp64)"
+    achieved = alg_bytes / (mean_us * 1e-6) / 1e9
+    # what an EMPTY start/stop event pair measures on this stream: each timed burst carries that much ONCE (a burst is 2 x
+    # ~20 launches), reported for information
+    try:
+        ev_overhead = dev.event_overhead(200)
+    except Exception:  # noqa: BLE001
+        ev_overhead = None
+    # memory-side bytes per launch from the committed PMC passes; only valid for the build they were measured on
+    traffic, traffic_note = None, "no PMC file"
+    pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
+    if os.path.exists(pmc) and a.mesh == "L_50_R_5" and a.refine == 0:
+        with open(pmc) as fh:
+            pj = json.load(fh)
+        if pj.get("build_id") == dev.build_id and pj.get("launches_per_krylov_iteration") == launches:
+            traffic, traffic_note = pj.get("hbm_bytes_per_launch"), pj.get("source")
         else:
-            kernel_name = "k_bicg_a / k_bicg_b (fused BiCGStab half-iteration = SELL node-block SpMV + vector updates, fp64)"
-        if a.multilevel and a.refine > 0:
-            kernel_name = "k_bicg_a_mat / k_bicg_b_mat (tile kernels of the materialised vector form: SELL node-block SpMV staging one vector, fp64)"
-        achieved = alg_bytes / (mean_us * 1e-6) / 1e9
-        # what an EMPTY start/stop event pair measures on this stream: each timed burst carries that much ONCE (a burst is 2 x
-        # ~20 launches), reported for information
-        try:
-            ev_overhead = dev.event_overhead(200)
-        except Exception:  # noqa: BLE001
-            ev_overhead = None
-        # memory-side bytes per launch from the committed PMC passes; only valid for the build they were measured on
-        traffic, traffic_note = None, "no PMC file"
-        pmc = os.path.join(ROOT, "profiles", "spmv_pmc.json")
-        if os.path.exists(pmc) and a.mesh == "L_50_R_5" and a.refine == 0:
-            with open(pmc) as fh:
-                pj = json.load(fh)
-            if pj.get("build_id") == dev.build_id and pj.get("launches_per_krylov_iteration") == launches:
-                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), pj.get("source")
-            else:
-                traffic_note = "profiles/spmv_pmc.json was measured on build %s, this library is %s: dropped" % (pj.get("build_id"), dev.build_id)
-        out = {
-            "metric": "newton_iterations_per_sec", "value": its / dt, "unit": "Newton-iterations/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "reference inputs shipped in data/utilities (%s mesh, parameters_pore.yaml, bulk_soln_0.5KHCO3.yaml); "
-                    "deterministic, no RNG" % a.mesh,
-            "config": {"refine": a.refine, "n_vertices": nv,
-                       "preconditioner": ("node-block Jacobi + 8 slab aggregates + geometric multilevel term over %d nested meshes (V(1,1) cycles on the coarser levels)" % (a.refine + 1))
-                       if (a.multilevel and a.refine > 0) else "node-block Jacobi + 8 slab aggregates (two-level)",
-                       "workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
-                                   "(Newton rtol=atol=1e-4, omega=0.9, max 50; linear solve = two-level BiCGStab to "
-                                   "1e-10 relative residual)" % (a.mesh, a.steps - 1),
-                       "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,
-                       "krylov_iterations": kry,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
-                         "empty_event_pair_us": ev_overhead,   # information only: `achieved` uses the raw event time (conservative)
-                         "timing": "one HIP event pair around the first burst of every Nth solve (back-to-back live half-iterations); mean = elapsed / half-iterations, launch gaps included",
-                         "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
-                         "launches_per_krylov_iteration": launches, "multilevel_note": ml_note},
-        }
-        if world == 1:
-            out["scaling_note"] = "N = 1: one problem on one GPU; the field says weak because the contract has two values (at N > 1: strong = ONE problem partitioned, replicas = weak)"
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(run)
-        if world > 1:
-            out["replicas"] = {"metric": "newton_iterations_per_sec, %d independent L_50_R_5 problems, one per GPU (BASELINE configs[4] mapping)" % world,
-                               "value": its / dt, "ms_per_step": 1e3 * dt / a.steps, "newton_iterations": its, "krylov_iterations": kry, "scaling": "weak"}
-        return out
+            traffic_note = "profiles/spmv_pmc.json was measured on build %s, this library is %s: dropped" % (pj.get("build_id"), dev.build_id)
+    out = {
+        "metric": "newton_iterations_per_sec", "value": its / dt, "unit": "Newton-iterations/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "reference inputs shipped in data/utilities (%s mesh, parameters_pore.yaml, bulk_soln_0.5KHCO3.yaml); "
+                "deterministic, no RNG" % a.mesh,
+        "config": {"refine": a.refine, "n_vertices": nv,
+                   "preconditioner": ("node-block Jacobi + 8 slab aggregates + geometric multilevel term over %d nested meshes (V(1,1) cycles on the coarser levels)" % (a.refine + 1))
+                   if (a.multilevel and a.refine > 0) else "node-block Jacobi + 8 slab aggregates (two-level)",
+                   "workload": "3D MPNP_CO2ER_pore %s, 0.5 M KHCO3, K+, V=-1: time steps 0..%d from t=0 "
+                               "(Newton rtol=atol=1e-4, omega=0.9, max 50; linear solve = two-level BiCGStab to "
+                               "1e-10 relative residual)" % (a.mesh, a.steps - 1),
+                   "n_dofs": nd, "jacobian_nnz": dev.jacobian_nnz, "newton_iterations": its,
+                   "krylov_iterations": kry,
+                   "parallelism": "1 GPU" if world == 1 else "%d independent replicas, one per GPU (no collective)" % world},
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
+                     "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
+                     "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": mean_us,
+                     "empty_event_pair_us": ev_overhead,   # information only: `achieved` uses the raw event time (conservative)
+                     "timing": "one HIP event pair around the first burst of every Nth solve (back-to-back live half-iterations); mean = elapsed / half-iterations, launch gaps included",
+                     "launches_sampled": prof["sampled"], "launches_total": prof["launched"],
+                     "launches_per_krylov_iteration": launches, "multilevel_note": ml_note},
+    }
+    if world == 1:
+        out["scaling_note"] = "N = 1: one problem on one GPU; the field says weak because the contract has two values (at N > 1: strong = ONE problem partitioned, replicas = weak)"
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(run)
+    if world > 1:
+        out["replicas"] = {"metric": "newton_iterations_per_sec, %d independent L_50_R_5 problems, one per GPU (BASELINE configs[4] mapping)" % world,
+                           "value": its / dt, "ms_per_step": 1e3 * dt / a.steps, "newton_iterations": its, "krylov_iterations": kry, "scaling": "weak"}
+    return out
 
 
 def attach_partitioned(out, a, world, part):
