@@ -51,3 +51,40 @@ def test_banded_all_cores_leg_solves_the_same_system_as_superlu(boxpore):
     assert leg["solution_vs_superlu"] < 1e-8 and leg["threads"] >= 1 and leg["lu_seconds"] > 0
     kl, ku = leg["half_bandwidth_scalars"]
     assert 9 <= kl < prob.ndof // 4 and 9 <= ku < prob.ndof // 4   # slab order: a band, not the whole matrix
+    # the threaded node-block band LU (oracle/band_lu_omp.c) solves the same system
+    omp = leg["block_band_openmp"]
+    assert "error" not in omp, omp
+    assert omp["solution_vs_superlu"] < 1e-8 and omp["lu_seconds"] > 0
+    assert (omp["half_bandwidth_blocks"] + 1) * 9 > kl >= omp["half_bandwidth_blocks"] * 9 - 8
+
+
+def test_block_band_lu_is_thread_count_independent_and_reports_singular_blocks():
+    import band_lu
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, b, nf = 40, 6, 9
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j in range(max(0, i - b), min(n, i + b + 1)):
+            if i == j or rng.random() < 0.5:
+                blk = rng.standard_normal((nf, nf)) + (12.0 * np.eye(nf) if i == j else 0.0)
+                r, c = np.meshgrid(np.arange(nf), np.arange(nf), indexing="ij")
+                rows.append((i * nf + r).ravel()); cols.append((j * nf + c).ravel()); vals.append(blk.ravel())
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * nf, n * nf))
+    rhs = rng.standard_normal(n * nf)
+    pos = rng.permutation(n)          # any vertex order: the band just gets wider
+    x1, _, hb = band_lu.solve(A, rhs, pos, threads=1)
+    x4, _, _ = band_lu.solve(A, rhs, pos, threads=4)
+    assert np.array_equal(x1, x4)     # every block has one owner and one summation order, whatever the thread count
+    assert np.linalg.norm(A @ x1 - rhs) < 1e-10 * np.linalg.norm(rhs) and hb <= n - 1
+    Z = A.tolil(); Z[0:nf, :] = 0.0
+    try:
+        band_lu.solve(Z.tocsr(), rhs, np.arange(n))
+        raise AssertionError("singular diagonal block went unnoticed")
+    except RuntimeError as e:
+        assert "singular diagonal block 0" in str(e)
+
+
+def test_usable_cpus_is_within_the_machine():
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
