@@ -18,11 +18,15 @@ ap.add_argument("--load", type=str, default=None, help="checkpoint (npz: u, un, 
 ap.add_argument("--save", type=str, default=None, help="checkpoint written after EVERY step")
 ap.add_argument("--time-budget", type=float, default=0.0, help="stop cleanly after this many seconds of THIS call (0 = run to --steps)")
 a = ap.parse_args()
-nthreads = a.threads if a.threads > 0 else (os.cpu_count() or 1)
-for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ[k] = str(nthreads)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+if a.threads > 0:
+    nthreads = a.threads
+else:
+    import bench   # usable_cpus(): the cgroup quota, not os.cpu_count() (16 vs 256 on the one-GPU box)
+    nthreads = bench.usable_cpus()
+for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[k] = str(nthreads)
 import numpy as np
 import gmpnp_oracle as O
 from gmpnp_amd.mesh import read_dolfin_xml, resolve_mesh_path
