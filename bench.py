@@ -481,8 +481,10 @@ def main():
                 state["phase"] = "%s: set-up" % transport
                 err = None
                 try:
-                    prun = PoreRun(partition=(world, rank), device_kwargs={"device_id": local, "transport": transport,
-                                                                           "shared_device": int(shared)}, **common)
+                    dk = {"device_id": local, "transport": transport, "shared_device": int(shared)}
+                    if transport == "peer" and os.environ.get("GMPNP_BENCH_EXCHANGE_FORM"):   # A/B runs: 1 = separate exchange launches
+                        dk["exchange_form"] = int(os.environ["GMPNP_BENCH_EXCHANGE_FORM"])
+                    prun = PoreRun(partition=(world, rank), device_kwargs=dk, **common)
                 except Exception as e:  # noqa: BLE001
                     err = "%s: %s" % (type(e).__name__, str(e)[:300])
                 if agree(err is not None):
@@ -510,6 +512,8 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 res = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
                        "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport, "state_vs_single_gpu": rel}
+                if transport == "peer":   # 2 = the exchange rides inside the next half-iteration's launch, 1 = separate launches
+                    res["exchange_form"] = prun.sys.ps.exchange_form()
                 check["run"] = "pass"
                 tried.append({"transport": transport, "value": res["value"], "krylov_iterations": pkry})
                 if state["best"] is None or res["value"] > state["best"]["value"]:   # identical on every rank (all-reduced time)
@@ -629,7 +633,7 @@ def attach_partitioned(out, a, world, part):
                                          "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
                                          % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
         out["roofline"] = dict(out["roofline"], note="kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)")
-        out["partitioned"] = {k: part[k] for k in ("transport", "seconds", "transports_timed", "earlier_errors", "note", "transport_checks",
+        out["partitioned"] = {k: part[k] for k in ("transport", "exchange_form", "seconds", "transports_timed", "earlier_errors", "note", "transport_checks",
                                                    "state_vs_single_gpu", "watchdog") if k in part}
     else:
         out["partitioned"] = part or {"error": "not run (--replicas-only)"}

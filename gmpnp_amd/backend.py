@@ -31,7 +31,7 @@ EXPORTS = [
     "gmpnp_set_supg",
     "gmpnp_create_partition", "gmpnp_comm_unique_id", "gmpnp_comm_create", "gmpnp_comm_selftest", "gmpnp_comm_destroy", "gmpnp_group_create", "gmpnp_group_create_hosted",
     "gmpnp_group_peer_begin", "gmpnp_group_peer_connect",
-    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous", "gmpnp_group_selftest", "gmpnp_attach_coarse_level",
+    "gmpnp_group_destroy", "gmpnp_group_newton_solve", "gmpnp_group_assign_previous", "gmpnp_group_selftest", "gmpnp_group_set_exchange_form", "gmpnp_group_exchange_form", "gmpnp_attach_coarse_level",
     "gmpnp_project_gradient", "gmpnp_project_cellwise",
 ]
 COMM_ID_BYTES = 128
@@ -160,6 +160,9 @@ def load_library(path: str = None):
     lib.gmpnp_group_newton_solve.argtypes = [c_void_p, POINTER(CNewtonOptions), POINTER(CNewtonStats)]
     lib.gmpnp_group_assign_previous.argtypes = [c_void_p]
     lib.gmpnp_group_selftest.argtypes = [c_void_p, POINTER(c_double)]
+    lib.gmpnp_group_set_exchange_form.argtypes = [c_void_p, c_int32]
+    lib.gmpnp_group_exchange_form.argtypes = [c_void_p]
+    lib.gmpnp_group_exchange_form.restype = c_int32
     lib.gmpnp_attach_coarse_level.argtypes = [c_void_p, c_void_p, POINTER(c_int32), c_double, c_int32]
     lib.gmpnp_project_gradient.argtypes = [c_void_p, POINTER(c_double), c_double, POINTER(c_double), POINTER(CLinearStats)]
     lib.gmpnp_project_cellwise.argtypes = [c_void_p, c_int32, POINTER(c_double), POINTER(c_double), POINTER(CLinearStats)]

@@ -150,7 +150,7 @@ struct gmpnp_solver {
   bool matp = false;        // materialised vector form of the BiCGStab half-iterations (opts.vector_form; automatic above 768 MB of matrix)
   bool prereduce = false;   // unpartitioned, many tile slots per aggregate: k_dist_reduce feeds the coarse kernels (Ctx::dist)
   std::vector<int32_t> nb_rank, send_ptr, recv_ptr;   // neighbours; [n_neighbours + 1] offsets into the node lists
-  DevBuf<int32_t> send_nodes, recv_nodes;
+  DevBuf<int32_t> send_nodes, recv_nodes, tile_cols_x;
   DevBuf<double> sendbuf, recvbuf, red_i, red_a, red_b, red_norm;
   double* h_red = nullptr;   // pinned [8]: all-reduced ||b||^2 and status bits
   std::unique_ptr<gmpnp_projector> projector;
@@ -1366,6 +1366,12 @@ static int create_impl(const gmpnp_mesh_t* mesh, const gmpnp_model_t* model, con
       s->send_ptr.push_back((int32_t)sn.size()); s->recv_ptr.push_back((int32_t)rn.size());
     }
     HIP_TRY(s->send_nodes.upload(sn)); HIP_TRY(s->recv_nodes.upload(rn));
+    {  // the tiles' column lists with every ghost node replaced by -(its index in the receive list + 1): exchange-prologue launches
+      std::vector<int32_t> slot_of(nv, -1), tcx = t.tile_cols;
+      for (size_t k = 0; k < rn.size(); ++k) slot_of[rn[k]] = (int32_t)k;
+      for (auto& node : tcx) if (node >= 0 && node < nv && slot_of[node] >= 0) node = -(slot_of[node] + 1);
+      HIP_TRY(s->tile_cols_x.upload(tcx));
+    }
     const size_t wmax = (size_t)nf * nf;   // widest exchange: the inverse diagonal blocks of the ghost nodes
     HIP_TRY(s->sendbuf.alloc(std::max<size_t>(1, sn.size() * wmax))); HIP_TRY(s->recvbuf.alloc(std::max<size_t>(1, rn.size() * wmax)));
     HIP_TRY(s->red_norm.alloc(8));

@@ -41,22 +41,26 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const VecListW dst, int nve
 //   phase 3 (end of a solve)    out[d]                = sum_slot cpart_v[0][slot][d]                 (P^T y, left by k_restrict)
 // WT: the result leaves as an agent-scope write-through store (the exchange kernel: another workgroup, on any XCD, reads it
 // back in the same launch and later overwrites it — no address may be dirty in two L2s); else a plain store.
+// where output o of a phase comes from: `count` partials, `stride` doubles apart
+__device__ __forceinline__ const double* dist_reduce_source(const Ctx& c, int phase, int par, int o, int& count, int& stride) {
+  const int n = c.ncoarse;
+  const int nscal = phase == 1 ? 2 : (phase == 2 ? 4 : 0);
+  if (o < nscal) {
+    count = c.ntiles; stride = 1;
+    return phase == 1 ? (o == 0 ? c.part_a : c.part_rr) : c.part_b + (size_t)o * c.ntiles;
+  }
+  const int q = o - nscal, w = q / n, d = q - w * n;
+  const int nf = n / c.nagg, ag = d / nf;   // part[aggregate][slot][field] (cpart_index)
+  count = c.tile_slots; stride = nf;
+  return (phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
+          : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par])) + (size_t)ag * c.tile_slots * nf + (d - ag * nf);
+}
 template <bool WT = false>
 __device__ __forceinline__ void dist_reduce_block(const Ctx& c, int phase, int par, double* __restrict__ out, int o) {
   __shared__ double lds[4];
-  const int n = c.ncoarse, t = threadIdx.x;
-  const int nscal = phase == 1 ? 2 : (phase == 2 ? 4 : 0);
-  const double* p; int count, stride;
-  if (o < nscal) {
-    p = phase == 1 ? (o == 0 ? c.part_a : c.part_rr) : c.part_b + (size_t)o * c.ntiles;
-    count = c.ntiles; stride = 1;
-  } else {
-    const int q = o - nscal, w = q / n, d = q - w * n;
-    const int nf = n / c.nagg, ag = d / nf;   // part[aggregate][slot][field] (cpart_index)
-    p = (phase == 0 ? c.cpart_v[1] : phase == 3 ? c.cpart_v[0] : phase == 2 ? c.cpart_t
-         : (w == 0 ? c.cpart_v[par] : w == 1 ? c.cpart_r[par] : c.cpart_p[par])) + (size_t)ag * c.tile_slots * nf + (d - ag * nf);
-    count = c.tile_slots; stride = nf;
-  }
+  const int t = threadIdx.x;
+  int count, stride;
+  const double* p = dist_reduce_source(c, phase, par, o, count, stride);
   double v[1] = {0.0};
   for (int i0 = t; i0 < count; i0 += 8 * 256) {   // eight independent requests per thread and trip
     double w8[8];
@@ -140,10 +144,11 @@ __global__ __launch_bounds__(256) void k_zero_foreign_rows(double* __restrict__ 
 // slowest (it needs everybody's flag of exchange k to finish k, and a rank raises k only after it has consumed k - 1).
 // Mailbox layout (bytes): [flags: kPeerMax x 128] [recv-offset table: kPeerMax x int32 at 1024] [red at red_off: 2 x size x
 // red_cap doubles] [halo at halo_off: per neighbour segment j both parities side by side, (2 recv_ptr[j] + parity len_j) wmax].
-constexpr int kPeerMax = 8;       // ranks of a partition
+constexpr int kPeerMax = kXRanksMax;       // ranks of a partition
 constexpr int kPeerNbMax = 8;     // neighbours of one rank
-constexpr int kPeerFlagStride = 32;  // uint32 words between two flags (one 128-B line each)
+constexpr int kPeerFlagStride = kXFlagStride;  // uint32 words between two flags (one 128-B line each)
 constexpr size_t kPeerTableOff = 1024, kPeerRedOff = 2048;
+constexpr int kLLHaloNodes = 2048;   // ghost nodes the flagged-word area of a mailbox holds (3.5 MB); a rank with more uses the flag-based launches
 struct PeerArgs {
   unsigned char* box[kPeerMax];   // every rank's mailbox as mapped in THIS process (box[me]: the own allocation)
   int me, size;
@@ -286,6 +291,96 @@ __global__ __launch_bounds__(256) void k_dist_reduce_exchange(const Ctx c, int p
       vecs.p[v][(size_t)recv_nodes[k] * width + f] = ld_sys(src + i);
     }
   }
+}
+
+// ---- the exchange as the PROLOGUE of the next half-iteration's launch (peer transport, launches resident at once) --------------
+// k_dist_reduce_exchange between two fused half-iteration launches costs its 7 us (measured phase by phase, tools/xch_phases.py:
+// 1.3 us to sum the partials, 1.9 to drain the stores into the uncached mailboxes, 1.3 for the arrival counter, 0.5 + 0.8 for the
+// flags, 1.0 for the acquire fence, 1.1 to read the contributions back) and sits between the launches.  Here the exchange rides IN
+// FRONT of the coarse workgroups of the launch that needs it, and what travels is FLAGGED WORDS (ll_store / ll_wait in
+// gmpnp_kernels.h): no flag behind the data, hence no drain, no counter, no elected workgroup, no fence —
+//     [ nx exchange workgroups | nagg coarse workgroups | tiles ]
+//   exchange workgroups   one WAVE per output value sums the previous launch's partials (plain loads: a kernel boundary lies in
+//                         between) and stores the sum as flagged words into EVERY rank's mailbox; the other workgroups store the
+//                         boundary rows of the previous launch's vectors as flagged words into the neighbours' mailboxes.  That is
+//                         all: they wait for nobody.
+//   coarse workgroups     issue their loads, then poll exactly the words they need in this rank's mailbox — the contributions of
+//                         every rank to the few sums of their aggregate and to the scalars, added in rank order — and go on as ever;
+//   tiles                 as on one GPU; a tile with ghost columns reads those entries out of the mailbox behind the hand-over.
+// The sums and rows of an exchange stay in their slot (sequence number & 3) until the exchange after the next overwrites it: a
+// launch also reads what the exchange BEFORE its own delivered (half A: P^T v, r, p and the ghost rows of p, v), so nothing is ever
+// copied into red_a / red_b or into the vectors' ghost rows.  A rank can be one exchange ahead of a neighbour (it sends before it
+// waits) while that neighbour still reads the exchange before: three live slots, four provided.  Nothing waits for a higher block
+// index, so the launch drains whatever the residency.  k = 0 and everything outside the BiCGStab loop use the flag-based
+// launches above (their own sequence numbers and mailbox areas).
+struct XchArgs {
+  unsigned char* box[kPeerMax];           // every rank's mailbox as mapped in this process
+  int me, size;
+  unsigned seq;                           // number of this flagged-word exchange: the same on every rank, consecutive within a solve
+  size_t ll_red_off, ll_halo_off;         // byte offsets of the two flagged-word areas (the same on every rank)
+  int red_cap;
+  int n_nb, nb_rank[kPeerNbMax], send_ptr[kPeerNbMax + 1], peer_recv_ptr[kPeerNbMax];
+  int phase, par, nout, nvec, nsn, nx;    // nx = exchange workgroups = ceil(nout / 8) + ceil(nsn nvec NF / 512)
+  VecList vecs;
+  const int32_t* send_nodes;
+};
+inline int xch_workgroups(int nout, int nsn, int nvec, int nf) { return (nout + 7) / 8 + (nsn * nvec * nf + kKrylovThreads - 1) / kKrylovThreads; }
+
+template <int NF>
+__device__ __forceinline__ void xch_body(const Ctx& c, const XchArgs& x, const int wg, const int k) {
+  static_assert(3 * NF <= kLLRow, "three vectors of a ghost node per slot");
+  constexpr int nt = kKrylovThreads;
+  const int t = threadIdx.x, per = x.nvec * NF, slot = x.seq & (kLLSlots - 1);
+  const int nred = (x.nout + 7) / 8;
+  if (c.scal->done) return;   // a launch behind the end of the solve: nobody reads what it would send (the verdict is the same on every rank)
+  if (wg == 0 && x.phase == 2) GMPNP_XSTAMP(k, 0);
+  if (wg < nred) {
+    const int o = wg * 8 + (t >> 6), lane = t & 63;
+    if (o < x.nout) {   // wave-uniform
+      int count, stride;
+      const double* p = dist_reduce_source(c, x.phase, x.par, o, count, stride);
+      // twelve requests per lane in flight at once: the launches this form is used for are resident at once, i.e. at most
+      // 768 tiles (and as many slots) — one memory round trip for the whole sum, the loop only for anything larger
+      double v = 0.0;
+      for (int i0 = lane; i0 < count; i0 += 12 * 64) {
+        double w12[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) w12[u] = p[(size_t)min(i0 + u * 64, count - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v += (i0 + u * 64 < count) ? w12[u] : 0.0;
+      }
+      v = wave_sum(v);
+      if (wg == 0 && x.phase == 2) GMPNP_XSTAMP(k, 1);
+      if (lane < x.size)
+        ll_store(reinterpret_cast<unsigned long long*>(x.box[lane] + x.ll_red_off) + (((size_t)slot * x.size + x.me) * x.red_cap + o) * 2, v, x.seq);
+    }
+  } else {
+    const int i = (wg - nred) * nt + t;
+    if (i < x.nsn * per) {
+      const int f = i % NF, v = (i / NF) % x.nvec, ks = i / per;
+      int j = 0;
+      while (j + 1 < x.n_nb && ks >= x.send_ptr[j + 1]) ++j;
+      const int kr = x.peer_recv_ptr[j] + (ks - x.send_ptr[j]);   // the node's index in the NEIGHBOUR's receive list
+      ll_store(reinterpret_cast<unsigned long long*>(x.box[x.nb_rank[j]] + x.ll_halo_off) + (((size_t)kr * kLLSlots + slot) * kLLRow + v * NF + f) * 2,
+               x.vecs.p[v][(size_t)x.send_nodes[ks] * NF + f], x.seq);
+    }
+  }
+  if (wg == 0 && x.phase == 2) GMPNP_XSTAMP(k, 2);
+}
+
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads, 6) void k_half_a_x(const Ctx c, const int k, const unsigned target, const XchArgs x) {
+  const int b = (int)blockIdx.x - x.nx;
+  if (b < 0) xch_body<NF>(c, x, blockIdx.x, k);
+  else if (b < c.nagg) coarse_a_body<NF, true, true>(c, k, b, target);
+  else bicg_a_body<NF, true, false, true>(c, k, c.tile0 + xcd_tile(b - c.nagg, (int)gridDim.x - x.nx - c.nagg), target);
+}
+template <int NF>
+__global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b_x(const Ctx c, const int k, const unsigned target, const XchArgs x) {
+  const int b = (int)blockIdx.x - x.nx;
+  if (b < 0) xch_body<NF>(c, x, blockIdx.x, k);
+  else if (b < c.nagg) coarse_b_body<NF, true, true>(c, k, b, target);
+  else bicg_b_body<NF, true, false, true>(c, k, c.tile0 + xcd_tile(b - c.nagg, (int)gridDim.x - x.nx - c.nagg), target);
 }
 
 // In-process rehearsal transport: sum over the handles of one process, written back to all of them (fixed order)

@@ -97,6 +97,11 @@ struct gmpnp_group {
   std::vector<hipStream_t> own_stream;  // in-process mode: the handles' own streams, given back at destroy
   std::vector<std::vector<int>> peer_slot;  // in-process mode: peer_slot[d][j] = index of d in the neighbour list of d's neighbour j
   int last_iters = 0;                   // BiCGStab iterations of the previous solve (identical on every rank): sizes the first burst
+  // ... and those of the previous Newton solve BY NEWTON ITERATION (the k-th linear solve of a time step takes within an iteration
+  // or two of what the k-th of the step before took — 85 / 65 / 53 / 44 ... — while consecutive solves differ by tens): the first
+  // burst of a solve is sized by it, so that most solves end inside their first burst (a burst boundary is a device-to-host copy
+  // and a stream synchronisation: 30 us of idle GPU; an iteration launched behind the end of a solve costs 14 us)
+  int iters_by_newton[16] = {0};
   // Coarse operator of the two-level preconditioner: rebuilt (Galerkin product, one all-reduce, 72 x 72 inverse: 180 us in the
   // stream) for the first Newton iteration of a solve and every third one after it; in between the solves run with the
   // inverse they have — any coarse operator gives a valid right preconditioner (the single-GPU solver does the same with a
@@ -107,6 +112,11 @@ struct gmpnp_group {
   // peer-mailbox transport (gmpnp_group_peer_begin / _connect): one k_peer_exchange launch per collective, no library, no host step
   bool peer = false, peer_connected = false;
   unsigned* peer_counter = nullptr;                        // arrival counter of k_dist_reduce_exchange (device)
+  // exchange as the prologue of the next half-iteration's launch (k_half_a_x / k_half_b_x): possible when the launch WITH its exchange
+  // workgroups is resident at once; exchange_form 0 = use it when possible, 1 = separate exchange launches (gmpnp_group_set_exchange_form)
+  bool prologue_ok = false; int exchange_form = 0;
+  size_t ll_red_off = 0, ll_halo_off = 0;   // flagged-word areas of the mailbox (gmpnp_dist_kernels.h, XchArgs)
+  unsigned llseq = 0;                        // their sequence number (same on every rank: one per k_half_*_x launch)
   unsigned char* box = nullptr; size_t box_bytes = 0;   // own mailbox (uncached device memory)
   void* peer_map[kPeerMax] = {};                          // the other ranks' mailboxes as mapped here (IPC)
   PeerArgs pa{};
@@ -296,7 +306,7 @@ int group_setup(gmpnp_group* g, int mode, bool rebuild_coarse = true) {
 // random_shadow: the shadow vector of this pass is each handle's krand (filled by the caller) and (rhat, r_0) = shadow_rho0
 template <int NF>
 int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double atol, int maxit, gmpnp_linear_stats_t* st, bool sized_by_previous = true,
-                 bool random_shadow = false, double shadow_rho0 = 0.0) {
+                 bool random_shadow = false, double shadow_rho0 = 0.0, int predicted = 0) {
   const int use_coarse = (mode == GMPNP_LINEAR_BICGSTAB_TWOLEVEL) ? 1 : 0;
   const int n = g->dom[0]->ncoarse;
   KrylovScalars init{};
@@ -330,6 +340,45 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     // (the received rows are in place and the sums all-reduced when the previous launch ends, so the coarse workgroups can
     // ride in front of the tile workgroups as on one GPU wherever the whole launch is resident: 4 launches per iteration)
     const dim3 fg(s->t.nagg + s->t.own_ntiles);
+    if (s->fused_half && g->prologue_ok && g->exchange_form != 1) {
+      // TWO launches per iteration: the exchange of a launch's sums and boundary rows rides in front of the NEXT launch's coarse
+      // workgroups (gmpnp_dist_kernels.h, "exchange as the prologue").  A(0) needs nothing exchanged (the start-up collectives did it).
+      auto xargs = [&](int phase, int nout, const VecList& v, int nvec) {
+        XchArgs x{};
+        const PeerArgs& a = g->pa;
+        for (int q = 0; q < kPeerMax; ++q) x.box[q] = a.box[q];
+        x.me = a.me; x.size = a.size; x.seq = ++g->llseq; x.ll_red_off = g->ll_red_off; x.ll_halo_off = g->ll_halo_off; x.red_cap = a.red_cap;
+        x.n_nb = a.n_nb;
+        for (int j = 0; j < a.n_nb; ++j) { x.nb_rank[j] = a.nb_rank[j]; x.peer_recv_ptr[j] = a.peer_recv_ptr[j]; }
+        for (int j = 0; j <= a.n_nb; ++j) x.send_ptr[j] = a.send_ptr[j];
+        x.phase = phase; x.par = par; x.nout = nout; x.nvec = nvec; x.nsn = nsn; x.nx = xch_workgroups(nout, nsn, nvec, NF);
+        x.vecs = v; x.send_nodes = s->send_nodes.p;
+        return x;
+      };
+      auto xctx = [&](const XchArgs& x) {   // what the coarse workgroups and the boundary tiles of that launch poll
+        Ctx cc = s->c;
+        cc.xseq = x.seq; cc.xsize = x.size; cc.xcap = x.red_cap; cc.tile_cols_x = s->tile_cols_x.p;
+        cc.xll_red = reinterpret_cast<const unsigned long long*>(g->box + g->ll_red_off);
+        cc.xll_halo = reinterpret_cast<const unsigned long long*>(g->box + g->ll_halo_off);
+        return cc;
+      };
+      if (k == 0) hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, (unsigned)(++s->fused_seq));
+      else {   // prologue: what B(k-1) left (sums of phase 2, rows of s and t)
+        VecList vb{}; vb.p[0] = s->ks.p; vb.p[1] = s->kt.p;
+        const XchArgs x = xargs(2, 4 + n, vb, 2);
+        const Ctx cc = xctx(x);
+        hipLaunchKernelGGL((k_half_a_x<NF>), dim3(x.nx + fg.x), dim3(kKrylovThreads), 0, s->stream, cc, k, (unsigned)(++s->fused_seq), x);
+      }
+      {        // prologue: what A(k) left (sums of phase 1, rows of r, v, p)
+        VecList va{}; va.p[0] = s->kr.p; va.p[1] = s->c.kv[par]; va.p[2] = s->c.kp[par];
+        const XchArgs x = xargs(1, 2 + 3 * n, va, 3);
+        const Ctx cc = xctx(x);
+        hipLaunchKernelGGL((k_half_b_x<NF>), dim3(x.nx + fg.x), dim3(kKrylovThreads), 0, s->stream, cc, k, (unsigned)(++s->fused_seq), x);
+      }
+      ++k;
+      HIP_TRY(hipGetLastError());
+      return GMPNP_OK;
+    }
     if (s->fused_half) hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, (unsigned)(++s->fused_seq));
     else {
       hipLaunchKernelGGL((k_coarse_a<NF>), cg_peer, dim3(kCoarseThreads), 0, s->stream, s->c, k);
@@ -386,7 +435,7 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     // Bursts: every rank launches the SAME number of iterations (the schedule depends only on the previous solve's count and
     // on `done`, both identical on all ranks), then reads the device's verdict.  Iterations launched behind the end of the
     // solve exit at their first instruction; their collectives still pair up.
-    int burst = sized_by_previous ? std::max(2, (7 * g->last_iters) / 8) : 4;
+    int burst = predicted > 0 ? predicted + 1 : (sized_by_previous ? std::max(2, (7 * g->last_iters) / 8) : 4);
     gmpnp_solver* s0 = g->dom[0];
     while (true) {
       for (int it = 0; it < burst; ++it) { rc = iteration(); if (rc) return rc; }
@@ -493,8 +542,10 @@ int group_newton(gmpnp_group* g, const gmpnp_newton_options_t& o, gmpnp_newton_s
       // verdict comes from all-reduced sums, so every rank takes the same branch.
       bool random_shadow = false; double rho0 = 0.0;
       for (int attempt = 0;; ++attempt) {
+        const int hist = (attempt == 0 && !g->dom[0]->state_jumped && st.iterations < 16) ? g->iters_by_newton[st.iterations] : 0;
         rc = group_krylov<NF>(g, o.linear_solver, rstart, warm ? 0.0 : o.krylov_relative_tolerance, warm ? tol_abs : o.krylov_absolute_tolerance,
-                              o.krylov_maximum_iterations, &ls, st.iterations > 0 && attempt == 0, random_shadow, rho0);
+                              o.krylov_maximum_iterations, &ls, st.iterations > 0 && attempt == 0, random_shadow, rho0, hist);
+        if (attempt == 0 && rc == GMPNP_OK && st.iterations < 16) g->iters_by_newton[st.iterations] = ls.iterations;
         kry_total += ls.iterations;
         if (rc != GMPNP_ERR_LINEAR || attempt >= 4 || g->dom[0]->last_done != 3) break;
         if (warm && attempt >= 1) { warm = false; rstart = r; }
@@ -692,7 +743,12 @@ int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_han
   a.red_cap = (int)std::max<size_t>({n * n, 2 + 3 * n, (size_t)8});
   a.red_cap = (a.red_cap + 15) & ~15;
   a.wmax = handle->nf * handle->nf;
-  a.halo_off = kPeerRedOff + (size_t)2 * a.size * a.red_cap * sizeof(double);
+  // mailbox layout (every offset the same on every rank; only the last area's size differs): flags | table | all-reduce contributions
+  // | flagged-word sums [kLLSlots][size][red_cap] | flagged-word ghost rows [kLLHaloNodes][kLLSlots][kLLRow] (16 bytes a double) |
+  // ghost rows of the flag-based exchanges (2 parities, wmax doubles per node)
+  g->ll_red_off = kPeerRedOff + (size_t)2 * a.size * a.red_cap * sizeof(double);
+  g->ll_halo_off = g->ll_red_off + (size_t)kLLSlots * a.size * a.red_cap * 16;
+  a.halo_off = g->ll_halo_off + (size_t)kLLHaloNodes * kLLSlots * kLLRow * 16;
   a.n_nb = (int)handle->nb_rank.size();
   for (int j = 0; j < a.n_nb; ++j) a.nb_rank[j] = handle->nb_rank[j];
   for (int j = 0; j <= a.n_nb; ++j) { a.send_ptr[j] = handle->send_ptr[j]; a.recv_ptr[j] = handle->recv_ptr[j]; }
@@ -707,6 +763,16 @@ int gmpnp_group_peer_begin(gmpnp_solver* handle, gmpnp_group** out, char ipc_han
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMalloc((void**)&g->peer_counter, sizeof(unsigned)));
   HIP_TRY(hipMemset(g->peer_counter, 0, sizeof(unsigned)));
+  if (handle->fused_half && handle->nf == 9) {
+    // the exchange may ride in front of the next launch's coarse workgroups where that launch is STILL resident at once
+    int occ_a = 0, occ_b = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_half_a_x<9>, kKrylovThreads, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, k_half_b_x<9>, kKrylovThreads, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, handle->opts.device_id));
+    const int nsn = handle->send_ptr.empty() ? 0 : handle->send_ptr.back();
+    const int nx = std::max(xch_workgroups(2 + 3 * (int)n, nsn, 3, 9), xch_workgroups(4 + (int)n, nsn, 2, 9));
+    g->prologue_ok = handle->t.own_ntiles + handle->t.nagg + nx <= std::min(occ_a, occ_b) * cus && handle->recv_ptr.back() <= kLLHaloNodes;
+  }
   HIP_TRY(hipHostMalloc((void**)&g->h_peer_err, sizeof(int32_t)));
   *g->h_peer_err = 0;
   a.err = g->h_peer_err;
@@ -808,6 +874,16 @@ int gmpnp_group_selftest(gmpnp_group* g, double* max_error) {
   if (g->peer && *g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
   *max_error = err;
   return GMPNP_OK;
+}
+
+int gmpnp_group_set_exchange_form(gmpnp_group* g, int32_t form) {
+  if (!g || (form != 0 && form != 1)) return fail(GMPNP_ERR_INVALID, "bad arguments");
+  g->exchange_form = form;
+  return GMPNP_OK;
+}
+int32_t gmpnp_group_exchange_form(const gmpnp_group* g) {
+  if (!g) return -1;
+  return (g->peer && g->prologue_ok && g->exchange_form != 1 && g->dom[0]->fused_half) ? 2 : (g->peer ? 1 : 0);
 }
 
 int gmpnp_group_assign_previous(gmpnp_group* g) {

@@ -78,6 +78,10 @@ struct TileRec {
   int32_t pad_;
 };
 
+constexpr int kXFlagStride = 32;   // uint32 words between two ranks' flags in a peer mailbox (one 128-B line each)
+constexpr int kLLSlots = 4;        // flagged-word areas of a peer mailbox: slots by sequence number (a reader looks one exchange back, a writer may be one ahead)
+constexpr int kLLRow = 27;         // doubles per ghost node and slot there (three vectors of NF = 9)
+
 // Everything the kernels need, passed by value (kernarg segment).
 struct Ctx {
   // sizes
@@ -182,6 +186,15 @@ struct Ctx {
   double* red_i;                  // [ncoarse]          P^T r_0                                  (all-reduced over the ranks)
   double* red_a;                  // [2 + 3 ncoarse]    (rhat,v) ||r||^2 | P^T v | P^T r | P^T p
   double* red_b;                  // [4 + ncoarse]      (t,s) (t,t) (rhat,s) (rhat,t) | P^T t
+  // exchange as the PROLOGUE of a half-iteration's launch (peer transport, gmpnp_dist_kernels.h): the ranks' sums and boundary rows
+  // arrive in THIS rank's mailbox as flagged words (every 8-byte word = 32 bits of data + the exchange's sequence number), in the
+  // slot xseq & 3; the coarse workgroups and the boundary tiles poll the words they need — those of this launch's exchange (xseq)
+  // and of the one before (xseq - 1).  nullptr otherwise.
+  const unsigned long long* xll_red;    // [kLLSlots][xsize ranks][xcap][2 words]   contributions to the all-reduced sums
+  const unsigned long long* xll_halo;   // [receive-list index][kLLSlots][kLLRow][2 words]   ghost rows (r|s, v|t, p)
+  const int32_t* tile_cols_x;           // tile_cols with every ghost node replaced by -(k + 1), k = its index in the receive list
+  uint32_t xseq;
+  int32_t xsize, xcap;
   const double* stage_a;   // materialised form with a multilevel term: what half A / half B stage instead of p_k / s_k (else nullptr)
   const double* stage_b;
   const double* supg_rho;  // [nv][NS] nodal SUPG parameters (internal order) or nullptr: PNP stabilisation of reference 1D:597-722

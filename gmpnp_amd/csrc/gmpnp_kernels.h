@@ -1133,6 +1133,11 @@ constexpr int kStagePre = 2;  // staged x entries per thread requested up front 
 #else
 #define GMPNP_STAMP(i) do { } while (0)
 #endif
+#ifdef GMPNP_XTIMING  // development builds only: phase timestamps of the exchange-prologue launches of iteration 5 (tools/xch_phases.py)
+#define GMPNP_XSTAMP(k_, i) do { if (threadIdx.x == 0 && (k_) == 5) c.yc[kMaxCoarse * 16 + 32 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define GMPNP_XSTAMP(k_, i) do { } while (0)
+#endif
 // Early exit of a finished solve.  The requested values get a (never executed) use on the exit path: without it the
 // compiler sinks every request below this branch, i.e. behind the scalar round trip that fetches the flag.
 #define GMPNP_EXIT_IF_DONE(flag, keep_expr) do { if (flag) { if (c.ndof < 0) c.yc[0] = (keep_expr); return; } } while (0)
@@ -1165,7 +1170,7 @@ __device__ __forceinline__ void poll_finish(const Ctx& c, double rr, int iters, 
   poll_store(&c.poll->rr, rr); poll_store(&c.poll->iters, iters);
   __hip_atomic_store(&c.poll->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
+__device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq, unsigned long long budget = 200000000ull) {
   __shared__ int ticket_ok;
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
@@ -1178,7 +1183,7 @@ __device__ __forceinline__ bool wait_ticket(const Ctx& c, unsigned seq) {
       // 2 s at 100 MHz.  The flags cannot fail to arrive (coarse workgroups are dispatched first and wait for nobody); the
       // budget only has to outlast a time slice taken by another process sharing the GPU.  Ends the solve (later
       // launches exit at once).
-      if (wall_clock64() - t0 > 200000000ull) { ok = 0; if (lane == 0) { atomicOr(c.status, 8); c.scal->done = 3; poll_finish(c, c.scal->rr, c.scal->iters, 3); } break; }
+      if (wall_clock64() - t0 > budget) { ok = 0; if (lane == 0) { atomicOr(c.status, 8); c.scal->done = 3; poll_finish(c, c.scal->rr, c.scal->iters, 3); } break; }
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane == 0) ticket_ok = ok;
@@ -1203,14 +1208,81 @@ __device__ __forceinline__ double load_coherent(const int32_t* p) {
   return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Exchange-as-prologue launches (XCH; gmpnp_dist_kernels.h).  What the ranks send each other there travels as FLAGGED WORDS: a
+// double is two 8-byte words, each = 32 bits of it | the exchange's sequence number << 32, stored with one 8-byte system-scope store
+// into the receiver's mailbox (uncached memory).  A word is valid when its upper half equals the sequence number the reader expects:
+// no flag behind the data, no store drain, no fence, no counter — data and validity are ONE atomic object (the low-latency protocol
+// of the collective libraries).  A reader polls exactly the words it needs.  Budget: 12 s at 100 MHz (a rank that is gone); on
+// expiry the solve ends with status bit 8, like a hand-over that never comes.
+constexpr unsigned long long kXchBudget = 1200000000ull;
+__device__ __forceinline__ void ll_store(unsigned long long* dst, double v, uint32_t seq) {
+  const unsigned long long tag = (unsigned long long)seq << 32;
+  __hip_atomic_store(dst, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(dst + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// N doubles at once: all 2N words are requested together and re-requested together until every one carries its sequence number
+// (one memory round trip when everything has arrived, whatever N)
+template <int N>
+__device__ __forceinline__ void ll_wait_n(const Ctx& c, const unsigned long long* const (&src)[N], const uint32_t (&seq)[N], double (&out)[N]) {
+  unsigned long long w[N][2];
+  const unsigned long long t0 = wall_clock64();
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      w[i][0] = __hip_atomic_load(src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      w[i][1] = __hip_atomic_load(src[i] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ok = ok && (uint32_t)(w[i][0] >> 32) == seq[i] && (uint32_t)(w[i][1] >> 32) == seq[i];
+    if (ok) break;
+    if (wall_clock64() - t0 > kXchBudget) { atomicOr(c.status, 8); c.scal->done = 3; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = __hiloint2double((int)(uint32_t)w[i][1], (int)(uint32_t)w[i][0]);
+}
+// where rank q's contribution to entry i of the sums of exchange `seq` stands in this rank's mailbox
+__device__ __forceinline__ const unsigned long long* ll_red_word(const Ctx& c, uint32_t seq, int q, int i) {
+  return c.xll_red + (((size_t)(seq & (kLLSlots - 1)) * c.xsize + q) * c.xcap + i) * 2;
+}
+// ... and value f of vector v of the ghost node with receive-list index k, as sent by exchange `seq`
+__device__ __forceinline__ const unsigned long long* ll_ghost_word(const Ctx& c, uint32_t seq, int k, int v, int f, int nf) {
+  return c.xll_halo + (((size_t)k * kLLSlots + (seq & (kLLSlots - 1))) * kLLRow + v * nf + f) * 2;
+}
+constexpr int kXRanksMax = 8;   // ranks of a partition over the peer transport (= kPeerMax)
+// The all-reduce inside a coarse workgroup: NCON entries, thread (q, i) = q * NCON + i polls rank q's contribution to entry i —
+// every rank's words are in flight together — and thread i adds them up in RANK ORDER (the same order, hence the same bits, on
+// every rank and in every workgroup).  entry(i) -> (index into the exchange's sums, which exchange).  Two barriers.
+template <int NCON, class F>
+__device__ __forceinline__ void ll_allreduce(const Ctx& c, double* con /* [kXRanksMax * NCON] */, double* dst /* [NCON] */, F entry) {
+  const int t = threadIdx.x;
+  if (t < NCON * c.xsize) {
+    const int q = t / NCON, i = t - q * NCON;
+    int idx; uint32_t seq;
+    entry(i, idx, seq);
+    const unsigned long long* const src[1] = {ll_red_word(c, seq, q, idx)};
+    const uint32_t sq[1] = {seq};
+    double v[1];
+    ll_wait_n<1>(c, src, sq, v);
+    con[t] = v[0];
+  }
+  __syncthreads();
+  if (t < NCON) {
+    double acc = 0.0;
+    for (int q = 0; q < c.xsize; ++q) acc += con[q * NCON + t];
+    dst[t] = acc;
+  }
+}
+
 // ---- coarse kernels: scalars of the half-iteration, yc = Aci * (P^T p  or  P^T s) in column blocks ----------------
 // One workgroup per aggregate g.  It sums the per-tile restriction partials of ITS NF coarse dofs only (fixed order),
 // forms the NF entries of the coarse operand and writes the column-block product yc[g][:] = Aci[:, g-block] * operand_g;
 // the tile kernels add the nagg blocks for the few coarse dofs they prolong from (TileCoarse).  Every workgroup
 // reduces the scalar partials redundantly; workgroup 0 publishes the scalars.
-template <int NF, bool FUSED>
+template <int NF, bool FUSED, bool XCH = false>
 __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const int g, const unsigned target) {
-  __shared__ double cs[4 * NF];
+  __shared__ double cs[4 * NF + 4];
   __shared__ double lred[(kCoarseThreads / 64) * 4];
   KrylovScalars* sc = c.scal;
   const int t = threadIdx.x, n = c.ncoarse;
@@ -1218,6 +1290,7 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   const bool first = (k == 0);
   // all requests first (the `done` flag among them: a finished solve still issues them, then exits)
   GMPNP_STAMP(0);
+  if (XCH && g == 0) GMPNP_XSTAMP(k, 16);
   const int done_flag = sc->done;
   double acol[NF];
 #pragma unroll
@@ -1226,18 +1299,22 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   // Exact restrictions of the ACTUAL fine vectors of iteration k-1 (epilogue partials of A(k-1) and B(k-1)): the
   // coarse vectors are rebuilt from them every iteration, nothing accumulates on the coarse level.
   AggSlotSums<4, NF> ss;
-  psum.load(c.part_b, c.ntiles, c.ntiles);  // k = 0: stale values, not used
-  {  // P^T v_{k-1} (k = 0: P^T b from k_restrict), P^T t_{k-1}, P^T r_{k-1}, P^T p_{k-1}
+  if (!XCH) {   // (exchange-prologue launches get their sums out of the mailbox: the partials are the exchange workgroups' business)
+    psum.load(c.part_b, c.ntiles, c.ntiles);  // k = 0: stale values, not used
+    // P^T v_{k-1} (k = 0: P^T b from k_restrict), P^T t_{k-1}, P^T r_{k-1}, P^T p_{k-1}
     const double* const arr[4] = {c.cpart_v[par ^ 1], first ? c.cpart_v[par ^ 1] : c.cpart_t,
                                   first ? c.cpart_v[par ^ 1] : c.cpart_r[par ^ 1], first ? c.cpart_v[par ^ 1] : c.cpart_p[par ^ 1]};
     ss.load(arr, n, c.tile_slots, g);
   }
   const double sc_alpha = sc->alpha, sc_rho0 = sc->rho[0], sc_rho1 = sc->rho[1];
-  { double keep = ss.r[0];
+  { double keep = 0.0;
+    if (!XCH) {
+      keep = ss.r[0];
 #pragma unroll
-    for (int u = 1; u < 9; ++u) keep += ss.r[u];
+      for (int u = 1; u < 9; ++u) keep += ss.r[u];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) keep += psum.r[q][0] + psum.r[q][1];
+      for (int q = 0; q < 4; ++q) keep += psum.r[q][0] + psum.r[q][1];
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) keep += acol[f];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
@@ -1247,7 +1324,18 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   GMPNP_STAMP(1);
   // ONE barrier: restriction sums of this aggregate and per-wave scalar sums go to LDS, then every thread finishes alone
   if (c.dist) {  // partitioned solve: the sums over all ranks' tiles were all-reduced into red_i / red_a / red_b
-    if (c.use_coarse && t < 4 * NF) {
+    if (XCH && g == 0) GMPNP_XSTAMP(k, 17);
+    if (XCH) {
+      // half A in the exchange-prologue form: the sums of phase 2 (what B(k-1) left: (t,s) (t,t) (rhat,s) (rhat,t) | P^T t) are those of
+      // THIS launch's exchange, the sums of phase 1 (P^T v, r, p of A(k-1)) those of the exchange before; 4 NF + 4 threads poll one each
+      __shared__ double con[kXRanksMax * (4 * NF + 4)];
+      ll_allreduce<4 * NF + 4>(c, con, cs, [&](int i, int& idx, uint32_t& seq) {
+        const int which = i / NF, f = i - which * NF, d = g * NF + f;
+        if (i >= 4 * NF) { idx = i - 4 * NF; seq = c.xseq; }
+        else if (which == 1) { idx = 4 + d; seq = c.xseq; }
+        else { idx = 2 + (which == 0 ? 0 : which == 2 ? n : 2 * n) + d; seq = c.xseq - 1u; }
+      });
+    } else if (c.use_coarse && t < 4 * NF) {
       const int which = t / NF, f = t - which * NF, d = g * NF + f;
       cs[t] = first ? c.red_i[d] : (which == 0 ? c.red_a[2 + d] : which == 1 ? c.red_b[4 + d] : which == 2 ? c.red_a[2 + n + d] : c.red_a[2 + 2 * n + d]);
     }
@@ -1257,15 +1345,20 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   }
   __syncthreads();
   GMPNP_STAMP(2);
+  if (XCH && g == 0) GMPNP_XSTAMP(k, 18);
   if (!first) {
     double tot[4];
-    if (c.dist) { tot[0] = c.red_b[0]; tot[1] = c.red_b[1]; tot[2] = c.red_b[2]; tot[3] = c.red_b[3]; }
+    if (c.dist) {
+      if (XCH) { tot[0] = cs[4 * NF]; tot[1] = cs[4 * NF + 1]; tot[2] = cs[4 * NF + 2]; tot[3] = cs[4 * NF + 3]; }
+      else { tot[0] = c.red_b[0]; tot[1] = c.red_b[1]; tot[2] = c.red_b[2]; tot[3] = c.red_b[3]; }
+    }
     else PartialSums<4>::reduce_final(lred, tot);
     omega = tot[0] / tot[1];
     rho_new = tot[2] - omega * tot[3];
     beta = (rho_new / rho_old) * (alpha / omega);
   }
   GMPNP_STAMP(3);
+  if (XCH && g == 0) GMPNP_XSTAMP(k, 19);
   if (g == 0 && t == 0) { store_coherent<FUSED>(&sc->omega, omega); store_coherent<FUSED>(&sc->beta, beta); sc->rho[par] = rho_new; }
   if (!c.use_coarse) { publish_ticket<FUSED>(c, target, g); return; }
   GMPNP_STAMP(4);
@@ -1282,11 +1375,12 @@ __device__ __forceinline__ void coarse_a_body(const Ctx& c, const int k, const i
   }
   publish_ticket<FUSED>(c, target, g);
   GMPNP_STAMP(5);
+  if (XCH && g == 0) GMPNP_XSTAMP(k, 20);
 }
 
-template <int NF, bool FUSED>
+template <int NF, bool FUSED, bool XCH = false>
 __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const int g, const unsigned target) {
-  __shared__ double cs[2 * NF];
+  __shared__ double cs[2 * NF + 2];
   __shared__ double lred[(kCoarseThreads / 64) * 2];
   KrylovScalars* sc = c.scal;
   const int t = threadIdx.x, n = c.ncoarse;
@@ -1297,25 +1391,33 @@ __device__ __forceinline__ void coarse_b_body(const Ctx& c, const int k, const i
 #pragma unroll
   for (int f = 0; f < NF; ++f) acol[f] = c.Aci[(size_t)min(t, n - 1) * n + g * NF + f];
   PartialSums<2> psum;  // part_a and part_rr are adjacent halves of one buffer: stride ntiles
-  psum.load(c.part_a, c.ntiles, c.ntiles);
   AggSlotSums<2, NF> ss;
-  { const double* const arr[2] = {c.cpart_v[par], c.cpart_r[par]}; ss.load(arr, n, c.tile_slots, g); }
-  { double keep = ss.r[0] + psum.r[0][0] + psum.r[1][0];
+  if (!XCH) { psum.load(c.part_a, c.ntiles, c.ntiles); const double* const arr[2] = {c.cpart_v[par], c.cpart_r[par]}; ss.load(arr, n, c.tile_slots, g); }
+  { double keep = 0.0;
+    if (!XCH) {
+      keep = ss.r[0] + psum.r[0][0] + psum.r[1][0];
 #pragma unroll
-    for (int u = 1; u < 9; ++u) keep += ss.r[u];
-    keep += (psum.r[0][1] + psum.r[1][1]);
+      for (int u = 1; u < 9; ++u) keep += ss.r[u];
+      keep += (psum.r[0][1] + psum.r[1][1]);
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) keep += acol[f];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (c.dist) {
-    if (c.use_coarse && t < 2 * NF) { const int which = t / NF, f = t - which * NF; cs[t] = c.red_a[2 + which * n + g * NF + f]; }
+    if (XCH) {   // half B: the sums of phase 1 ((rhat,v) ||r||^2 | P^T v | P^T r | ...) are those of THIS launch's exchange
+      __shared__ double con[kXRanksMax * (2 * NF + 2)];
+      ll_allreduce<2 * NF + 2>(c, con, cs, [&](int i, int& idx, uint32_t& seq) {
+        const int which = i / NF, f = i - which * NF;
+        idx = i >= 2 * NF ? i - 2 * NF : 2 + which * n + g * NF + f; seq = c.xseq;
+      });
+    } else if (c.use_coarse && t < 2 * NF) { const int which = t / NF, f = t - which * NF; cs[t] = c.red_a[2 + which * n + g * NF + f]; }
   } else {
     if (c.use_coarse) ss.to_lds(cs, n, c.tile_slots);
     psum.reduce_partial(lred, c.part_a, c.ntiles, c.ntiles);
   }
   __syncthreads();
   double tot[2];
-  if (c.dist) { tot[0] = c.red_a[0]; tot[1] = c.red_a[1]; }
+  if (c.dist) { tot[0] = XCH ? cs[2 * NF] : c.red_a[0]; tot[1] = XCH ? cs[2 * NF + 1] : c.red_a[1]; }
   else PartialSums<2>::reduce_final(lred, tot);
   const double rv = tot[0], rr = tot[1];
   int done = 0;
@@ -1346,9 +1448,13 @@ __device__ __forceinline__ void st_out(double* p, double v) { __hip_atomic_store
 // the own-row updates of y and r; the tile stages ONE vector at its column nodes instead of recomputing p from four (s from
 // two).  Pays where the operand gathers cost HBM / Infinity-Cache bandwidth (twice-refined meshes: a tile's four staged vectors
 // are as many bytes as its matrix slice), not on the reference meshes, where one more launch per half-iteration costs more.
-template <int NF, bool FUSED, bool MAT = false>
+// XCH (partitioned solve over the peer transport, exchange workgroups in front of this launch's coarse ones): the ghost entries of
+// the staged vectors are not read from the vectors (whose ghost rows nobody keeps current in this form) but out of the mailbox, as
+// flagged words of this launch's exchange and of the one before (ll_ghost), behind the hand-over; boundary tiles only.
+template <int NF, bool FUSED, bool MAT = false, bool XCH = false>
 __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int tile, const unsigned target) {
   static_assert(!(FUSED && MAT), "the materialised form has its own launches");
+  static_assert(!XCH || FUSED, "the exchange prologue belongs to the fused launch form");
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[3][kSlicesPerTile][64];  // v, r, p of the tile's rows
@@ -1364,6 +1470,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
   const int par = k & 1, n = c.ncoarse;
   const bool first = (k == 0);
   GMPNP_STAMP(0);
+  if (XCH && tile == c.tile0) GMPNP_XSTAMP(k, 24);
   const int done_flag = sc->done;
   const double alpha = sc->alpha;
   double omega = 0.0, beta = 0.0;
@@ -1382,7 +1489,7 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int cl = min((t + u * kKrylovThreads) / NF, c.col_stride - 1);  // padding entries of the list point at node 0
-    st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
+    st_col[u] = (XCH ? c.tile_cols_x : c.tile_cols)[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];   // XCH: ghost nodes are -(receive-list index + 1)
   }
   TileCoarse<NF> tcs;
   tcs.load_index(c, tile);
@@ -1394,7 +1501,11 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    const unsigned off = ((unsigned)st_col[u] * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
+    const bool gh = XCH && st_col[u] < 0;
+    // XCH: a staged GHOST entry (its values come out of the mailbox) keeps its receive-list index + 1 above the slot number in st_agg
+    if (XCH && gh && q < nst) st_agg[u] |= -st_col[u] << 8;
+    // (a ghost entry requests an owned row instead: the vectors' ghost rows are not kept up to date in this form)
+    const unsigned off = ((unsigned)(gh ? c.own_node0 : st_col[u]) * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
     st_s[u] = ld_off(sfirst, off);
     if (MAT) { st_t[u] = 0.0; st_p[u] = 0.0; st_v[u] = 0.0; }
     else { st_t[u] = ld_off(c.kt, off); st_p[u] = ld_off(po, off); st_v[u] = ld_off(vo, off); }  // k = 0: only st_s is used
@@ -1420,14 +1531,29 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
 #pragma unroll
       for (int j = 0; j < NF; ++j) keep += rows.av[u][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
+  if (XCH && tile == c.tile0) GMPNP_XSTAMP(k, 25);
   if (FUSED) {  // scalars and coarse products of THIS launch's coarse workgroups
-    if (!wait_ticket(c, target)) return;
+    if (!wait_ticket(c, target, XCH ? kXchBudget + 200000000ull : 200000000ull)) return;
+    if (XCH && tile == c.tile0) GMPNP_XSTAMP(k, 26);
     // the two scalars: ONE wave asks (one request instead of eight per tile on the line every tile reads at this moment), the
     // others get them through LDS behind the barrier that follows anyway
     __shared__ double hand[2];
     double w0 = 0.0, b0 = 0.0;
     if (wv == 0) { w0 = load_coherent(&sc->omega); b0 = load_coherent(&sc->beta); }
     tcs.template load_values<true>(c);
+    if (XCH) {   // ghost entries (boundary tiles only): s and t as sent by THIS launch's exchange, p_old and v_old by the one before
+#pragma unroll
+      for (int u = 0; u < kStagePre; ++u)
+        if (st_agg[u] >> 8) {
+          const int q = t + u * kKrylovThreads, f = q - (q / NF) * NF, gk = (st_agg[u] >> 8) - 1;
+          const unsigned long long* const src[4] = {ll_ghost_word(c, c.xseq, gk, 0, f, NF), ll_ghost_word(c, c.xseq, gk, 1, f, NF),
+                                                    ll_ghost_word(c, c.xseq - 1u, gk, 1, f, NF), ll_ghost_word(c, c.xseq - 1u, gk, 2, f, NF)};
+          const uint32_t sq[4] = {c.xseq, c.xseq, c.xseq - 1u, c.xseq - 1u};
+          double g4[4];
+          ll_wait_n<4>(c, src, sq, g4);
+          xs[q] = g4[0]; xt[q] = g4[1]; st_v[u] = g4[2]; st_p[u] = g4[3];
+        }
+    }
     if (t == 0) { hand[0] = w0; hand[1] = b0; }
     if (c.use_coarse) tcs.to_lds(c, ycl);
     __syncthreads();
@@ -1443,18 +1569,31 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     const int q = t + u * kKrylovThreads;
     if (q < nst) {
       const double pj = (first || MAT) ? st_s[u] : (xs[q] - omega * xt[q]) + beta * (st_p[u] - omega * st_v[u]);
-      xs[q] = pj + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
+      xs[q] = pj + (uc ? ycl[(XCH ? st_agg[u] & 0xff : st_agg[u]) * NF + (q - (q / NF) * NF)] : 0.0);
     }
   }
   if (wv < 6) own[wv][lane] = own_q;
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
-    const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    const double pj = MAT ? matsrc[idx] : first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
+    const int node = (XCH ? c.tile_cols_x : c.tile_cols)[c0 + cl];
+    double pj;
+    if (XCH && node < 0) {
+      const int gk = -node - 1;
+      const unsigned long long* const src[4] = {ll_ghost_word(c, c.xseq, gk, 0, f, NF), ll_ghost_word(c, c.xseq, gk, 1, f, NF),
+                                                ll_ghost_word(c, c.xseq - 1u, gk, 1, f, NF), ll_ghost_word(c, c.xseq - 1u, gk, 2, f, NF)};
+      const uint32_t sq[4] = {c.xseq, c.xseq, c.xseq - 1u, c.xseq - 1u};
+      double g4[4];
+      ll_wait_n<4>(c, src, sq, g4);
+      pj = (g4[0] - omega * g4[1]) + beta * (g4[3] - omega * g4[2]);
+    } else {
+      const size_t idx = (size_t)node * NF + f;
+      pj = MAT ? matsrc[idx] : first ? c.kr[idx] : (c.ks[idx] - omega * c.kt[idx]) + beta * (po[idx] - omega * vo[idx]);
+    }
     xs[q] = pj + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
   GMPNP_STAMP(3);
+  if (XCH && tile == c.tile0) GMPNP_XSTAMP(k, 28);
   red[wv][lane] = rows.dot(c, xs);
   __syncthreads();
   GMPNP_STAMP(4);
@@ -1495,15 +1634,17 @@ __device__ __forceinline__ void bicg_a_body(const Ctx& c, const int k, const int
     for (int q = 0; q < kSlicesPerTile; ++q) { a0 += dpart[q][0]; a1 += dpart[q][1]; }
     st_out(&c.part_a[tile], a0); st_out(&c.part_rr[tile], a1);
   }
+  if (XCH && tile == c.tile0) { __syncthreads(); GMPNP_XSTAMP(k, 27); }
 #ifdef GMPNP_TIMING
   __syncthreads();
   GMPNP_STAMP(5);
 #endif
 }
 
-template <int NF, bool FUSED, bool MAT = false>
+template <int NF, bool FUSED, bool MAT = false, bool XCH = false>
 __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int tile, const unsigned target) {
   static_assert(!(FUSED && MAT), "the materialised form has its own launches");
+  static_assert(!XCH || FUSED, "the exchange prologue belongs to the fused launch form");
   constexpr int NW = kKrylovWaves;
   __shared__ double red[kSlicesPerTile * NW][64];
   __shared__ double outv[kSlicesPerTile][64];
@@ -1526,7 +1667,7 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int cl = min((t + u * kKrylovThreads) / NF, c.col_stride - 1);  // padding entries of the list point at node 0
-    st_col[u] = c.tile_cols[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
+    st_col[u] = (XCH ? c.tile_cols_x : c.tile_cols)[c0 + cl]; st_agg[u] = c.tile_colslot[c0 + cl];
   }
   TileCoarse<NF> tcs;
   tcs.load_index(c, tile);
@@ -1538,7 +1679,9 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    const unsigned off = ((unsigned)st_col[u] * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
+    const bool gh = XCH && st_col[u] < 0;
+    if (XCH && gh && q < nst) st_agg[u] |= -st_col[u] << 8;   // see bicg_a_body
+    const unsigned off = ((unsigned)(gh ? c.own_node0 : st_col[u]) * NF + (unsigned)(q - (q / NF) * NF)) * 8u;
     st_r[u] = ld_off(MAT ? ((MAT && c.stage_b) ? c.stage_b : c.ks) : c.kr, off); st_v[u] = MAT ? 0.0 : ld_off(vn, off);   // MAT: s_k was written by k_vec_b (+ the multilevel term)
   }
   const int own_r = rows.row;  // inactive lanes: row 0
@@ -1553,11 +1696,23 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
       for (int j = 0; j < NF; ++j) keep += rows.av[u][j];
     GMPNP_EXIT_IF_DONE(done_flag, keep); }
   if (FUSED) {
-    if (!wait_ticket(c, target)) return;
+    if (!wait_ticket(c, target, XCH ? kXchBudget + 200000000ull : 200000000ull)) return;
     __shared__ double hand[2];   // see bicg_a_body
     double d0 = 0.0, a0 = 0.0;
     if (wv == 0) { d0 = load_coherent(&sc->done_next); a0 = load_coherent(&sc->alpha); }
     tcs.template load_values<true>(c);
+    if (XCH) {   // ghost entries (boundary tiles only): r and v as sent by THIS launch's exchange
+#pragma unroll
+      for (int u = 0; u < kStagePre; ++u)
+        if (st_agg[u] >> 8) {
+          const int q = t + u * kKrylovThreads, f = q - (q / NF) * NF, gk = (st_agg[u] >> 8) - 1;
+          const unsigned long long* const src[2] = {ll_ghost_word(c, c.xseq, gk, 0, f, NF), ll_ghost_word(c, c.xseq, gk, 1, f, NF)};
+          const uint32_t sq[2] = {c.xseq, c.xseq};
+          double g2[2];
+          ll_wait_n<2>(c, src, sq, g2);
+          st_r[u] = g2[0]; st_v[u] = g2[1];
+        }
+    }
     if (t == 0) { hand[0] = d0; hand[1] = a0; }
     if (c.use_coarse) tcs.to_lds(c, ycl);
     __syncthreads();
@@ -1575,13 +1730,24 @@ __device__ __forceinline__ void bicg_b_body(const Ctx& c, const int k, const int
 #pragma unroll
   for (int u = 0; u < kStagePre; ++u) {
     const int q = t + u * kKrylovThreads;
-    if (q < nst) xs[q] = (MAT ? st_r[u] : st_r[u] - alpha * st_v[u]) + (uc ? ycl[st_agg[u] * NF + (q - (q / NF) * NF)] : 0.0);
+    if (q < nst) xs[q] = (MAT ? st_r[u] : st_r[u] - alpha * st_v[u]) + (uc ? ycl[(XCH ? st_agg[u] & 0xff : st_agg[u]) * NF + (q - (q / NF) * NF)] : 0.0);
   }
   if (wv < 3) own[wv][lane] = own_q;
   for (int q = t + kStagePre * kKrylovThreads; q < nst; q += kKrylovThreads) {
     const int cl = q / NF, f = q - cl * NF;
-    const size_t idx = (size_t)c.tile_cols[c0 + cl] * NF + f;
-    xs[q] = (MAT ? ((MAT && c.stage_b) ? c.stage_b : c.ks)[idx] : c.kr[idx] - alpha * vn[idx]) + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
+    const int node = (XCH ? c.tile_cols_x : c.tile_cols)[c0 + cl];
+    double sj;
+    if (XCH && node < 0) {
+      const unsigned long long* const src[2] = {ll_ghost_word(c, c.xseq, -node - 1, 0, f, NF), ll_ghost_word(c, c.xseq, -node - 1, 1, f, NF)};
+      const uint32_t sq[2] = {c.xseq, c.xseq};
+      double g2[2];
+      ll_wait_n<2>(c, src, sq, g2);
+      sj = g2[0] - alpha * g2[1];
+    } else {
+      const size_t idx = (size_t)node * NF + f;
+      sj = MAT ? ((MAT && c.stage_b) ? c.stage_b : c.ks)[idx] : c.kr[idx] - alpha * vn[idx];
+    }
+    xs[q] = sj + (uc ? ycl[c.tile_colslot[c0 + cl] * NF + f] : 0.0);
   }
   __syncthreads();
   red[wv][lane] = rows.dot(c, xs);

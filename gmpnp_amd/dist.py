@@ -178,11 +178,13 @@ class PartitionedSolver:
     The Krylov and Newton loops run in the library; Python only scatters / gathers states and per-step boundary values."""
 
     def __init__(self, prob: Problem, nparts: int, rank: int = None, device_id: int = 0, n_global_aggregates: int = None,
-                 use_torch_dist: bool = True, transport: str = "rccl", **device_kwargs):
+                 use_torch_dist: bool = True, transport: str = "rccl", exchange_form: int = 0, **device_kwargs):
         """``transport`` (one rank per process only): "peer" — peer mailboxes: every collective is one kernel launch per rank
         that stores into the other ranks' IPC-mapped mailboxes (xGMI between GPUs; also works for ranks sharing a card);
         "rccl" — collectives inside the library over RCCL; "host" — the library stages every collective through pinned host
-        memory and calls back into ``torch.distributed`` (any backend, e.g. gloo)."""
+        memory and calls back into ``torch.distributed`` (any backend, e.g. gloo).  ``exchange_form`` (peer transport): 0 = the
+        exchange of a half-iteration rides inside the next launch where that launch is resident (2 launches per BiCGStab iteration),
+        1 = separate exchange launches (4); every rank must pass the same value (gmpnp_group_set_exchange_form)."""
         from ctypes import byref, c_void_p, create_string_buffer
         from . import backend
         self.backend = backend
@@ -231,6 +233,14 @@ class PartitionedSolver:
                 self.transport = "peer (failed)"
                 self.close()
                 raise RuntimeError("peer-mailbox transport not available: %s" % (err if err is not None else "another rank could not map a mailbox"))
+            # All ranks must run the SAME form (form 2 leaves the exchange behind the last launch of a solve out, so the sequence
+            # numbers of the two forms drift apart): a rank whose launch would not be resident with the exchange workgroups in
+            # front takes everybody back to separate launches.
+            self._check(self.lib.gmpnp_group_set_exchange_form(self._group, int(exchange_form)))
+            form = torch.tensor([int(self.lib.gmpnp_group_exchange_form(self._group))], dtype=torch.int32, device=dev)
+            tdist.all_reduce(form, op=tdist.ReduceOp.MIN)
+            if int(form[0]) != 2:
+                self._check(self.lib.gmpnp_group_set_exchange_form(self._group, 1))
             return
         if rank is not None and transport == "host":
             self._make_host_transport(rank, nparts)
@@ -348,6 +358,10 @@ class PartitionedSolver:
         err = c_double()
         self._check(self.lib.gmpnp_comm_selftest(self._comm, n, byref(err)))
         return err.value
+
+    def exchange_form(self):
+        """2 = the peer exchange rides inside the next half-iteration's launch, 1 = separate launches, 0 = another transport."""
+        return int(self.lib.gmpnp_group_exchange_form(self._group))
 
     def selftest(self):
         """One all-reduce and one ghost-row exchange with self-checking contents over this group's transport

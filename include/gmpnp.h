@@ -329,6 +329,15 @@ int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* opts,
  * of 5 doubles, one ghost-row message per neighbour): *max_error = largest deviation this process saw (0 expected).  Collective:
  * every rank calls it.  No reference counterpart (the reference is serial); it is the start-up check of BASELINE configs[3]. */
 int gmpnp_group_selftest(gmpnp_group* g, double* max_error);
+/* Peer-mailbox groups: how the exchange of a BiCGStab half-iteration's sums and boundary rows is launched.  form 0 (default) = in
+ * front of the NEXT half-iteration's coarse workgroups, inside that launch (two launches per iteration, as on one GPU), wherever
+ * the launch with its exchange workgroups is resident at once; form 1 = its own launch between the two (four per iteration).
+ * Every rank of a partition must run the same form: the caller compares gmpnp_group_exchange_form over the ranks after set-up and
+ * sets form 1 everywhere unless all of them report 2 (gmpnp_amd/dist.py does).  gmpnp_group_exchange_form: what a solve
+ * of this group will do — 2 = exchange inside the next launch, 1 = separate launches, 0 = not a peer-mailbox group.  No reference
+ * counterpart. */
+int gmpnp_group_set_exchange_form(gmpnp_group* g, int32_t form);
+int32_t gmpnp_group_exchange_form(const gmpnp_group* g);
 int gmpnp_group_assign_previous(gmpnp_group* g);
 
 /* Geometric multilevel term of the preconditioner on uniformly refined meshes (no reference counterpart: the reference solves

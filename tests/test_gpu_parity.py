@@ -1047,7 +1047,7 @@ def test_bench_two_ranks_share_the_card_over_peer_mailboxes():
     assert out["value"] > 0 and out["replicas"]["value"] > 0
 
 
-def _library_partition_worker(rank, world, port, out_dir, transport="host"):
+def _library_partition_worker(rank, world, port, out_dir, transport="host", exchange_form=0):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -1064,7 +1064,9 @@ def _library_partition_worker(rank, world, port, out_dir, transport="host"):
         mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
         prob, _ = pore_problem(pp, mesh)
         nv = mesh.num_vertices
-        with dist.PartitionedSolver(prob, world, rank=rank, transport=transport) as ps:
+        kw = {"exchange_form": exchange_form} if transport == "peer" else {}
+        with dist.PartitionedSolver(prob, world, rank=rank, transport=transport, **kw) as ps:
+            form = ps.exchange_form()
             assert ps.selftest() == 0.0     # gmpnp_group_selftest: self-checking all-reduce + ghost-row messages over THIS transport
             ps.set_state(np.zeros(nv * 9), np.tile(np.r_[np.ones(8), 0.0], nv))
             import time
@@ -1074,7 +1076,7 @@ def _library_partition_worker(rank, world, port, out_dir, transport="host"):
             ug = ps.get_state()
         if rank == 0:
             np.savez(os.path.join(out_dir, "libdist.npz"), u=ug, its=st["iterations"], res=np.array(st["residuals"]),
-                     kits=np.array(st["krylov_per_iteration"]), wall=wall)
+                     kits=np.array(st["krylov_per_iteration"]), wall=wall, form=form)
     finally:
         tdist.destroy_process_group()
 
@@ -1095,23 +1097,26 @@ def test_library_partitioned_solve_two_processes_on_one_card(gpu_lib, tmp_path):
     assert d["kits"].sum() < 700     # the single-GPU solver needs about 450 BiCGStab iterations for this solve
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_peer_mailbox_transport_between_processes_on_one_card(gpu_lib, tmp_path, world):
+@pytest.mark.parametrize("world,exchange_form", [(2, 0), (4, 0), (2, 1), (4, 1)])
+def test_peer_mailbox_transport_between_processes_on_one_card(gpu_lib, tmp_path, world, exchange_form):
     """The peer-mailbox transport between real PROCESSES: every rank maps the others' mailboxes through IPC handles, every
     collective of the partitioned Newton solve is one k_peer_exchange launch that stores into the peers' mailboxes and waits on
     its own flags (no RCCL, no host step).  The ranks share the test box's one GPU, so the stores do not cross xGMI here; the
     protocol (handles, mapping, sequence numbers, parity slots, flag waits between kernels of different processes) is the
-    multi-GPU one.  Against the serial golden step."""
+    multi-GPU one.  Against the serial golden step.  exchange_form 0: the exchange of a half-iteration rides in front of the NEXT
+    launch's coarse workgroups (k_half_a_x / k_half_b_x: two launches per BiCGStab iteration; the boundary tiles re-read their ghost
+    rows behind the hand-over, on whatever XCD they run); 1: its own launch (k_dist_reduce_exchange)."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 400) + 47 + world
-    mp.spawn(_library_partition_worker, args=(world, port, str(tmp_path), "peer"), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 400) + 47 + world + 10 * exchange_form
+    mp.spawn(_library_partition_worker, args=(world, port, str(tmp_path), "peer", exchange_form), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
     d = np.load(os.path.join(str(tmp_path), "libdist.npz"))
+    assert int(d["form"]) == (2 if exchange_form == 0 else 1)   # the launches of these partitions are resident with the exchange in front
     assert int(d["its"]) == int(g["newton_its"][0])
     assert relerr(d["u"], g["states"][0]) < 1e-8
     assert np.allclose(d["res"], g["residuals"][0][: len(d["res"])], rtol=1e-4)
     assert d["kits"].sum() < 700
-    print("peer transport, %d ranks on one card: %d BiCGStab iterations in %.1f ms" % (world, int(d["kits"].sum()), 1e3 * float(d["wall"])))
+    print("peer transport (exchange form %d), %d ranks on one card: %d BiCGStab iterations in %.1f ms" % (int(d["form"]), world, int(d["kits"].sum()), 1e3 * float(d["wall"])))
 
 
 def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
