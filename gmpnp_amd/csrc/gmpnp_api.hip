@@ -821,12 +821,20 @@ int tri_solve(gmpnp_solver* s, const double* rhs) {
   hipLaunchKernelGGL((k_tri_extract<NF>), dim3(grid_for(s->t.nv * NF * NF, kVecBlock)), dim3(kVecBlock), 0, s->stream,
                      s->c, s->tri[0], s->tri_kpos.p, rhs);
   const int nl = (int)s->tri.size();
-  for (int l = 0; l + 1 < nl; ++l)
+  // the top of the pyramid (every level whose upper neighbour has at most kBcrTailRows rows) is ONE launch: k_bcr_tail
+  int l0 = nl - 1;
+  while (l0 > 0 && s->tri[l0].n <= kBcrTailRows && nl - l0 < kBcrTailLevels) --l0;   // tail = levels l0 .. nl-1 (tri[l0+1].n <= kBcrTailRows)
+  for (int l = 0; l < l0; ++l)
     hipLaunchKernelGGL((k_bcr_forward<NF>), dim3(grid_for(s->tri[l + 1].n, 4)), dim3(64), 0, s->stream, s->tri[l],
                        s->tri[l + 1], s->status.p);
-  hipLaunchKernelGGL((k_bcr_top<NF>), dim3(1), dim3(64), 0, s->stream, s->tri[nl - 1], s->status.p);
-  for (int l = nl - 2; l >= 0; --l)
-    hipLaunchKernelGGL((k_bcr_backward<NF>), dim3(grid_for(s->tri[l].n, kVecBlock)), dim3(kVecBlock), 0, s->stream,
+  {
+    TriTail tt{};
+    tt.nlev = nl - l0;
+    for (int l = l0; l < nl; ++l) tt.lv[l - l0] = s->tri[l];
+    hipLaunchKernelGGL((k_bcr_tail<NF>), dim3(1), dim3(kBcrTailThreads), 0, s->stream, tt, s->status.p);
+  }
+  for (int l = l0 - 1; l >= 0; --l)
+    hipLaunchKernelGGL((k_bcr_backward<NF>), dim3(grid_for(s->tri[l].n * NF, kVecBlock)), dim3(kVecBlock), 0, s->stream,
                        s->tri[l], s->tri[l + 1]);
   HIP_TRY(hipGetLastError());
   return GMPNP_OK;

@@ -2114,11 +2114,17 @@ struct TriLevel {
 
 // Solve Dm X = [Lm | Um | bm] for row j of level lv with EIGHT LANES per system: lane r (< NF) of the 8-lane group
 // holds row r of the augmented matrix in registers, W[0..NF) = Dm row, W[NF..NC) = right-hand sides.  Gauss-Jordan
-// with partial pivoting; pivot search and row broadcasts are shuffles inside the group.  On return W[NF..NC) of
-// lane r is row r of Dm^{-1}[Lm | Um | bm].  Every lane of the wave must call it (inactive groups pass on = false).
+// with partial pivoting, rows stay where they are: in step k the lane with the largest |W[k]| among the rows not used yet
+// is the pivot row (the search is three shuffle rounds on ONE 64-bit key: the bit pattern of |W[k]| with its last three
+// mantissa bits replaced by 7 - lane, so that equal values go to the lower lane), its row is broadcast once per column and
+// eliminated from all other rows; lane k notes where variable k ended up and one last shuffle per right-hand side brings the
+// solution rows home.  169 shuffles per system instead of the 308 of the row-swapping form (two broadcasts per column): the
+// chain of a reduction level is mostly these shuffles (9.8 -> 8.2 us per level on the 50 um mesh).  On return W[NF..NC) of lane r
+// is row r of Dm^{-1}[Lm | Um | bm].  Every lane of the wave must call it (inactive groups pass on = false).
 template <int NF>
 __device__ inline bool tri_group_solve(const TriLevel& lv, int j, bool on, int r, double (&W)[3 * NF + 1]) {
   constexpr int NC = 3 * NF + 1;
+  static_assert(NF <= 8, "one lane per row of an 8-lane group");
   const bool rowon = on && r < NF;
   const int jc = on ? j : 0, rc = r < NF ? r : 0;
 #pragma unroll
@@ -2127,41 +2133,45 @@ __device__ inline bool tri_group_solve(const TriLevel& lv, int j, bool on, int r
     W[cI] = lv.D[off]; W[NF + cI] = lv.L[off]; W[2 * NF + cI] = lv.U[off];
   }
   W[3 * NF] = lv.b[(size_t)rc * lv.n + jc];
-  if (!rowon) {  // identity row: never chosen as a pivot for another row, harmless in the shuffles
+  if (!rowon) {  // identity row: never chosen as a pivot for another column, harmless in the shuffles
 #pragma unroll
     for (int cI = 0; cI < NC; ++cI) W[cI] = (cI == r && r < NF) ? 1.0 : 0.0;
   }
-  bool bad = false;
+  bool bad = false, used = r >= NF;
+  int home = r;   // lane that ends up holding the solution row of variable r
 #pragma unroll
   for (int k = 0; k < NF; ++k) {
-    double v = (r < NF && r >= k) ? fabs(W[k]) : -1.0; int idx = r;
+    unsigned long long key = used ? 0ull : (((unsigned long long)__double_as_longlong(fabs(W[k])) & ~7ull) | (unsigned long long)(7 - r));
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(v, o, 8); const int oi = __shfl_xor(idx, o, 8);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      const int olo = __shfl_xor((int)(unsigned)key, o, 8), ohi = __shfl_xor((int)(unsigned)(key >> 32), o, 8);
+      const unsigned long long ok_ = ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo;
+      key = ok_ > key ? ok_ : key;
     }
-    bad |= !(v > 0.0);
-    // rows k and idx swap places (lane k takes the pivot row, lane idx the old row k), then scale / eliminate
-    const double ip = 1.0 / __shfl(W[k], idx, 8);
-    const double oldk_k = __shfl(W[k], k, 8);
-    const double f = ((r == idx) ? oldk_k : W[k]) * ip;
+    const int p = 7 - (int)(key & 7ull);
+    bad |= (key >> 3) == 0ull;   // the largest candidate is (all but) zero
+    const double ip = 1.0 / __shfl(W[k], p, 8);
+    const double f = (r == p) ? 0.0 : W[k] * ip;
 #pragma unroll
     for (int cI = k + 1; cI < NC; ++cI) {
-      const double from_p = __shfl(W[cI], idx, 8), from_k = __shfl(W[cI], k, 8);
-      const double mine = (r == idx) ? from_k : W[cI];
-      W[cI] = (r == k) ? from_p * ip : mine - f * from_p;
+      const double from_p = __shfl(W[cI], p, 8);
+      W[cI] = (r == p) ? W[cI] * ip : W[cI] - f * from_p;
     }
-    W[k] = (r == k) ? 1.0 : 0.0;  // column k is done (keeps later pivot searches of lanes < k out via r >= k anyway)
+    W[k] = (r == p) ? 1.0 : 0.0;
+    used = used || (r == p);
+    home = (r == k) ? p : home;
   }
+#pragma unroll
+  for (int cI = NF; cI < NC; ++cI) W[cI] = __shfl(W[cI], home, 8);
   return !(on && bad);
 }
 
 // One level of the reduction.  16 lanes per row ih of the upper level: lanes 0-7 eliminate the left neighbour
 // (row 2ih-1 of the lower level), lanes 8-15 the right one (2ih+1); lane r of each half owns row r of the 7x7 blocks.
 template <int NF>
-__global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, int32_t* status) {
+__device__ __forceinline__ void bcr_forward_row(const TriLevel& lo, const TriLevel& hi, int32_t* status, const int ih_raw) {
   constexpr int NC = 3 * NF + 1;
-  const int t = threadIdx.x, ih_raw = blockIdx.x * 4 + (t >> 4);
+  const int t = threadIdx.x;
   const int side = (t >> 3) & 1, r = t & 7;
   const bool rowok = ih_raw < hi.n;
   const int ih = rowok ? ih_raw : 0, i = 2 * ih;
@@ -2215,10 +2225,14 @@ __global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, in
   }
   if (!ok) atomicOr(status, 2);
 }
+template <int NF>
+__global__ __launch_bounds__(64) void k_bcr_forward(TriLevel lo, TriLevel hi, int32_t* status) {
+  bcr_forward_row<NF>(lo, hi, status, blockIdx.x * 4 + ((int)threadIdx.x >> 4));
+}
 
 // top of the pyramid: one row, x = D^{-1} b
 template <int NF>
-__global__ __launch_bounds__(64) void k_bcr_top(TriLevel top, int32_t* status) {
+__device__ __forceinline__ void bcr_top_row(const TriLevel& top, int32_t* status) {
   constexpr int NC = 3 * NF + 1;
   const int t = threadIdx.x, r = t & 7;
   double W[NC];
@@ -2226,29 +2240,57 @@ __global__ __launch_bounds__(64) void k_bcr_top(TriLevel top, int32_t* status) {
   if (t < NF) top.x[t] = W[3 * NF];
   if (!ok) atomicOr(status, 2);
 }
+template <int NF>
+__global__ __launch_bounds__(64) void k_bcr_top(TriLevel top, int32_t* status) { bcr_top_row<NF>(top, status); }
 
+// One level of the way back: x of the even rows is the upper level's, an odd row j gets x_j = bi_j - Li_j x_{j-1} - Ui_j x_{j+1}.
+// One THREAD per (row, field): its 2 NF + 1 loads are one round trip (one thread per row ran NF of them one after the other:
+// 8 us per level instead of 3).
+template <int NF>
+__device__ __forceinline__ void bcr_backward_entry(const TriLevel& lo, const TriLevel& hi, const int q) {
+  if (q >= lo.n * NF) return;
+  const int r = q / lo.n, j = q - r * lo.n;   // j fastest: the loads of a wave are contiguous
+  if ((j & 1) == 0) { lo.x[(size_t)r * lo.n + j] = hi.x[(size_t)r * hi.n + (j >> 1)]; return; }
+  const bool has_r = (j + 1 < lo.n);
+  double li[NF], ui[NF], xl[NF], xr[NF];
+#pragma unroll
+  for (int cI = 0; cI < NF; ++cI) {
+    li[cI] = lo.Li[(size_t)(r * NF + cI) * lo.n + j]; ui[cI] = lo.Ui[(size_t)(r * NF + cI) * lo.n + j];
+    xl[cI] = hi.x[(size_t)cI * hi.n + ((j - 1) >> 1)];
+    xr[cI] = has_r ? hi.x[(size_t)cI * hi.n + ((j + 1) >> 1)] : 0.0;
+  }
+  double sacc = lo.bi[(size_t)r * lo.n + j];
+#pragma unroll
+  for (int cI = 0; cI < NF; ++cI) sacc -= li[cI] * xl[cI] + ui[cI] * xr[cI];
+  lo.x[(size_t)r * lo.n + j] = sacc;
+}
 template <int NF>
 __global__ __launch_bounds__(kVecBlock) void k_bcr_backward(TriLevel lo, TriLevel hi) {
-  const int j = blockIdx.x * kVecBlock + threadIdx.x;
-  if (j >= lo.n) return;
-  if ((j & 1) == 0) {
-#pragma unroll
-    for (int r = 0; r < NF; ++r) lo.x[(size_t)r * lo.n + j] = hi.x[(size_t)r * hi.n + (j >> 1)];
-    return;
+  bcr_backward_entry<NF>(lo, hi, blockIdx.x * kVecBlock + threadIdx.x);
+}
+
+// The TOP of the pyramid in one launch: the levels whose upper neighbour has at most kBcrTailRows rows, the single-row solve, and the
+// same levels on the way back — seven launches become one WAVE that walks through them with a barrier in between (a level's
+// results are read by the same wave: its own CU's cache serves them).  One wave and no more: the forward step of a level is a chain
+// of shuffles through the CU's LDS crossbar, and the waves of ONE workgroup share one crossbar where the waves of separate launches
+// have a CU each — measured on the 50 um mesh (whole solve): per-level launches 160.6 us, tail of the levels up to 4 rows in one wave
+// 156.2, up to 16 rows in four waves 168, up to 47 rows in eight waves 225.  The arithmetic is that of the per-level kernels (same
+// device functions).
+constexpr int kBcrTailRows = 4, kBcrTailLevels = 8, kBcrTailThreads = 64;   // ONE wave: its shuffles have the CU's LDS crossbar to themselves
+struct TriTail { TriLevel lv[kBcrTailLevels + 1]; int nlev; };   // lv[0] = the lowest level of the tail ... lv[nlev - 1] = the single row
+template <int NF>
+__global__ __launch_bounds__(kBcrTailThreads) void k_bcr_tail(const TriTail tt, int32_t* status) {
+  const int t = threadIdx.x;
+  for (int l = 0; l + 1 < tt.nlev; ++l) {
+    for (int ih0 = 0; ih0 < tt.lv[l + 1].n; ih0 += kBcrTailThreads / 16)   // (uniform trip count; rows beyond the level's end are masked inside)
+      bcr_forward_row<NF>(tt.lv[l], tt.lv[l + 1], status, ih0 + (t >> 4));
+    __syncthreads();
   }
-  double xl[NF], xr[NF];
-  const bool has_r = (j + 1 < lo.n);
-#pragma unroll
-  for (int r = 0; r < NF; ++r) {
-    xl[r] = hi.x[(size_t)r * hi.n + ((j - 1) >> 1)];
-    xr[r] = has_r ? hi.x[(size_t)r * hi.n + ((j + 1) >> 1)] : 0.0;
-  }
-  for (int r = 0; r < NF; ++r) {
-    double s = lo.bi[(size_t)r * lo.n + j];
-#pragma unroll
-    for (int cI = 0; cI < NF; ++cI)
-      s -= lo.Li[(size_t)(r * NF + cI) * lo.n + j] * xl[cI] + lo.Ui[(size_t)(r * NF + cI) * lo.n + j] * xr[cI];
-    lo.x[(size_t)r * lo.n + j] = s;
+  if (t < 64) bcr_top_row<NF>(tt.lv[tt.nlev - 1], status);
+  __syncthreads();
+  for (int l = tt.nlev - 2; l >= 0; --l) {
+    for (int q = t; q < tt.lv[l].n * NF; q += kBcrTailThreads) bcr_backward_entry<NF>(tt.lv[l], tt.lv[l + 1], q);
+    __syncthreads();
   }
 }
 
