@@ -265,13 +265,14 @@ def edl50_case(device_id, steps=100, warmup=3, cpu=True):
                "config": {"workload": "1D MPNP_CO2ER_EDL, 1D_variable_50um_mesh_5990, K+, 0.1 M KHCO3, V=-1: the %d dry-run steps "
                                       "(Newton rtol=atol=1e-4, omega=1, max 50; linear solve = block cyclic reduction, direct)" % steps,
                           "n_vertices": nv, "n_dofs": nd, "newton_iterations": its},
-               "roofline": {"bound": "hbm", "kernel": "1D direct solve: k_tri_extract + %d levels of k_bcr_forward, k_bcr_top, %d levels of "
-                                                      "k_bcr_backward (one launch each)" % (levels - 1, levels - 1),
+               "roofline": {"bound": "hbm", "kernel": "1D direct solve, block cyclic reduction over %d levels: k_tri_extract, k_bcr_forward per level, k_bcr_tail "
+                                                      "(the levels of up to 4 rows, the single row, and back: one wave), k_bcr_backward per level" % (levels - 1),
                             "algorithmic_bytes_per_solve": alg_bytes, "mean_solve_us": solve_us,
                             "achieved": alg_bytes / (solve_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                             "frac": alg_bytes / (solve_us * 1e-6) / 1e9 / 8000.0, "traffic": None,
-                            "note": "a chain of ~26 dependent launches over 7.7 MB that halves at every level: launch-latency bound, "
-                                    "not bandwidth bound; timed with one HIP event pair around 50 back-to-back solves"}}
+                            "note": "a chain of ~20 dependent launches over 7.7 MB that halves at every level, each a pivoted 7x7 solve by "
+                                    "shuffles inside 8-lane groups: latency and LDS-crossbar bound, not bandwidth bound; timed with one HIP event "
+                                    "pair around 50 back-to-back solves"}}
     finally:
         run.sys.close()
     if cpu:
