@@ -383,6 +383,49 @@ __global__ __launch_bounds__(kKrylovThreads, 6) void k_half_b_x(const Ctx c, con
   else bicg_b_body<NF, true, false, true>(c, k, c.tile0 + xcd_tile(b - c.nagg, (int)gridDim.x - x.nx - c.nagg), target);
 }
 
+// Self-check of the flagged-word areas over the transport itself (gmpnp_group_selftest): every rank stores (rank + 1)(i + 1), i < 5, into
+// every rank's sums area and sender * 1e6 + k into the first value of node k of every neighbour's ghost-row area, then polls what the
+// others sent and compares.  err_out[0] = largest deviation seen by this rank (a word that never arrives: status bit 8 as in a solve,
+// and the deviation of whatever stands there).  One workgroup.
+__global__ __launch_bounds__(kKrylovThreads) void k_xch_selftest(const Ctx c, const XchArgs x, const PeerArgs a, double* __restrict__ err_out) {
+  __shared__ double lds[kKrylovThreads / 64];
+  const int t = threadIdx.x, slot = x.seq & (kLLSlots - 1);
+  if (t < 5)
+    for (int q = 0; q < x.size; ++q)
+      ll_store(reinterpret_cast<unsigned long long*>(x.box[q] + x.ll_red_off) + (((size_t)slot * x.size + x.me) * x.red_cap + t) * 2, (double)(x.me + 1) * (t + 1), x.seq);
+  for (int j = 0; j < x.n_nb; ++j)
+    for (int ks = x.send_ptr[j] + t; ks < x.send_ptr[j + 1]; ks += kKrylovThreads) {
+      const int kr = x.peer_recv_ptr[j] + (ks - x.send_ptr[j]);
+      ll_store(reinterpret_cast<unsigned long long*>(x.box[x.nb_rank[j]] + x.ll_halo_off) + (((size_t)kr * kLLSlots + slot) * kLLRow) * 2, 1e6 * x.me + (ks - x.send_ptr[j]), x.seq);
+    }
+  double err = 0.0;
+  if (t < 5) {
+    double acc = 0.0;
+    for (int q = 0; q < x.size; ++q) {
+      const unsigned long long* const src[1] = {ll_red_word(c, x.seq, q, t)};
+      const uint32_t sq[1] = {x.seq};
+      double v[1];
+      ll_wait_n<1>(c, src, sq, v);
+      acc += v[0];
+    }
+    err = fabs(acc - 0.5 * x.size * (x.size + 1) * (t + 1));
+  }
+  for (int j = 0; j < a.n_nb; ++j)
+    for (int k = a.recv_ptr[j] + t; k < a.recv_ptr[j + 1]; k += kKrylovThreads) {
+      const unsigned long long* const src[1] = {ll_ghost_word(c, x.seq, k, 0, 0, 9)};
+      const uint32_t sq[1] = {x.seq};
+      double v[1];
+      ll_wait_n<1>(c, src, sq, v);
+      err = fmax(err, fabs(v[0] - (1e6 * a.nb_rank[j] + (k - a.recv_ptr[j]))));
+    }
+  // largest deviation of the workgroup (max over the lanes by shuffles, over the waves through LDS)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) err = fmax(err, __shfl_xor(err, o, 64));
+  if ((t & 63) == 0) lds[t >> 6] = err;
+  __syncthreads();
+  if (t == 0) { double m = 0.0; for (int w = 0; w < kKrylovThreads / 64; ++w) m = fmax(m, lds[w]); err_out[0] = m; }
+}
+
 // In-process rehearsal transport: sum over the handles of one process, written back to all of them (fixed order)
 struct PtrList { double* p[8]; };
 __global__ __launch_bounds__(256) void k_local_allreduce(const PtrList bufs, int nb, int n) {

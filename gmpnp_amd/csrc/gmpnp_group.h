@@ -143,6 +143,29 @@ int peer_exchange(gmpnp_group* g, double* red, int n_red, size_t per) {
   return GMPNP_OK;
 }
 
+// ---- flagged-word exchange (exchange-prologue launches, gmpnp_dist_kernels.h): arguments of the next one, and what its readers poll ----
+XchArgs make_xch_args(gmpnp_group* g, int phase, int par, int nout, const VecList& v, int nvec) {
+  gmpnp_solver* s = g->dom[0];
+  XchArgs x{};
+  const PeerArgs& a = g->pa;
+  for (int q = 0; q < kPeerMax; ++q) x.box[q] = a.box[q];
+  x.me = a.me; x.size = a.size; x.seq = ++g->llseq; x.ll_red_off = g->ll_red_off; x.ll_halo_off = g->ll_halo_off; x.red_cap = a.red_cap;
+  x.n_nb = a.n_nb;
+  for (int j = 0; j < a.n_nb; ++j) { x.nb_rank[j] = a.nb_rank[j]; x.peer_recv_ptr[j] = a.peer_recv_ptr[j]; }
+  for (int j = 0; j <= a.n_nb; ++j) x.send_ptr[j] = a.send_ptr[j];
+  x.phase = phase; x.par = par; x.nout = nout; x.nvec = nvec;
+  x.vecs = v; x.send_nodes = s->send_nodes.p;
+  return x;
+}
+Ctx xch_ctx(gmpnp_group* g, const XchArgs& x) {
+  gmpnp_solver* s = g->dom[0];
+  Ctx cc = s->c;
+  cc.xseq = x.seq; cc.xsize = x.size; cc.xcap = x.red_cap; cc.tile_cols_x = s->tile_cols_x.p;
+  cc.xll_red = reinterpret_cast<const unsigned long long*>(g->box + g->ll_red_off);
+  cc.xll_halo = reinterpret_cast<const unsigned long long*>(g->box + g->ll_halo_off);
+  return cc;
+}
+
 // ---- collectives over the local handles ------------------------------------------------------------------------------------
 template <class F>
 int group_allreduce(gmpnp_group* g, F buf_of, int n) {
@@ -343,25 +366,8 @@ int group_krylov(gmpnp_group* g, int mode, double bnorm, double rtol, double ato
     if (s->fused_half && g->prologue_ok && g->exchange_form != 1) {
       // TWO launches per iteration: the exchange of a launch's sums and boundary rows rides in front of the NEXT launch's coarse
       // workgroups (gmpnp_dist_kernels.h, "exchange as the prologue").  A(0) needs nothing exchanged (the start-up collectives did it).
-      auto xargs = [&](int phase, int nout, const VecList& v, int nvec) {
-        XchArgs x{};
-        const PeerArgs& a = g->pa;
-        for (int q = 0; q < kPeerMax; ++q) x.box[q] = a.box[q];
-        x.me = a.me; x.size = a.size; x.seq = ++g->llseq; x.ll_red_off = g->ll_red_off; x.ll_halo_off = g->ll_halo_off; x.red_cap = a.red_cap;
-        x.n_nb = a.n_nb;
-        for (int j = 0; j < a.n_nb; ++j) { x.nb_rank[j] = a.nb_rank[j]; x.peer_recv_ptr[j] = a.peer_recv_ptr[j]; }
-        for (int j = 0; j <= a.n_nb; ++j) x.send_ptr[j] = a.send_ptr[j];
-        x.phase = phase; x.par = par; x.nout = nout; x.nvec = nvec; x.nsn = nsn; x.nx = xch_workgroups(nout, nsn, nvec, NF);
-        x.vecs = v; x.send_nodes = s->send_nodes.p;
-        return x;
-      };
-      auto xctx = [&](const XchArgs& x) {   // what the coarse workgroups and the boundary tiles of that launch poll
-        Ctx cc = s->c;
-        cc.xseq = x.seq; cc.xsize = x.size; cc.xcap = x.red_cap; cc.tile_cols_x = s->tile_cols_x.p;
-        cc.xll_red = reinterpret_cast<const unsigned long long*>(g->box + g->ll_red_off);
-        cc.xll_halo = reinterpret_cast<const unsigned long long*>(g->box + g->ll_halo_off);
-        return cc;
-      };
+      auto xargs = [&](int phase, int nout, const VecList& v, int nvec) { XchArgs x = make_xch_args(g, phase, par, nout, v, nvec); x.nsn = nsn; x.nx = xch_workgroups(nout, nsn, nvec, NF); return x; };
+      auto xctx = [&](const XchArgs& x) { return xch_ctx(g, x); };
       if (k == 0) hipLaunchKernelGGL((k_half_a<NF>), fg, dim3(kKrylovThreads), 0, s->stream, s->c, k, (unsigned)(++s->fused_seq));
       else {   // prologue: what B(k-1) left (sums of phase 2, rows of s and t)
         VecList vb{}; vb.p[0] = s->ks.p; vb.p[1] = s->kt.p;
@@ -872,6 +878,22 @@ int gmpnp_group_selftest(gmpnp_group* g, double* max_error) {
       for (int k = s->recv_ptr[j]; k < s->recv_ptr[j + 1]; ++k) err = std::max(err, std::fabs(h[k] - (1e6 * s->nb_rank[j] + (k - s->recv_ptr[j]))));
   }
   if (g->peer && *g->h_peer_err) return fail(GMPNP_ERR_HIP, "peer transport: a rank's flag did not arrive within 5 s");
+  if (g->peer && g->prologue_ok && g->exchange_form != 1 && g->dom[0]->fused_half) {
+    // ... and the flagged-word areas the exchange-prologue launches of a solve use (k_xch_selftest), over the same mapping
+    gmpnp_solver* s = g->dom[0];
+    XchArgs x = make_xch_args(g, 0, 0, 0, VecList{}, 0);
+    Ctx cc = xch_ctx(g, x);
+    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+    hipLaunchKernelGGL(k_xch_selftest, dim3(1), dim3(kKrylovThreads), 0, s->stream, cc, x, g->pa, s->red_norm.p);
+    HIP_TRY(hipGetLastError());
+    double xerr = 0.0; int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&xerr, s->red_norm.p, sizeof xerr, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(&st, s->status.p, sizeof st, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemsetAsync(s->status.p, 0, sizeof(int32_t), s->stream));
+    if (st & 8) return fail(GMPNP_ERR_HIP, "peer transport: a flagged word of another rank did not arrive within 12 s");
+    err = std::max(err, xerr);
+  }
   *max_error = err;
   return GMPNP_OK;
 }

@@ -326,7 +326,9 @@ void gmpnp_group_destroy(gmpnp_group* g);
 int gmpnp_group_newton_solve(gmpnp_group* g, const gmpnp_newton_options_t* opts, gmpnp_newton_stats_t* stats);
 /* u_n.assign(u) on every local handle. */
 /* One pass of each collective of the partitioned solve over the group's own transport with self-checking contents (an all-reduce
- * of 5 doubles, one ghost-row message per neighbour): *max_error = largest deviation this process saw (0 expected).  Collective:
+ * of 5 doubles, one ghost-row message per neighbour; on a peer-mailbox group that will run its solves with the exchange inside the
+ * next launch, the same contents once more through the flagged-word areas those launches use): *max_error = largest deviation this
+ * process saw (0 expected).  Collective:
  * every rank calls it.  No reference counterpart (the reference is serial); it is the start-up check of BASELINE configs[3]. */
 int gmpnp_group_selftest(gmpnp_group* g, double* max_error);
 /* Peer-mailbox groups: how the exchange of a BiCGStab half-iteration's sums and boundary rows is launched.  form 0 (default) = in
