@@ -227,7 +227,7 @@ def banded_leg(O, prob, u0, un):
     return out
 
 
-def edl50_case(device_id, steps=100, warmup=3, cpu=True):
+def edl50_case(device_id, steps=100, warmup=3, cpu=True, repeats=1):
     """BASELINE configs[1]: reference 1D/MPNP_CO2ER_EDL.py with its defaults (K+, 0.1 M KHCO3, MPNP, V = -1, 50 um mesh of 5,991
     vertices, 7 fields = 41,937 dofs), the 100 dry-run steps of 1D:256-268.  A step = one Newton solve on the device (element
     pass, gathers, block-cyclic-reduction direct solve, update) + the step glue (vertex values back, u_n.assign(u))."""
@@ -245,13 +245,19 @@ def edl50_case(device_id, steps=100, warmup=3, cpu=True):
 
         for _ in range(warmup):
             run.step(verbose=False)
-        reset()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run.step(verbose=False)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # `repeats` > 1 (the secondary measurement inside the 3D line): the window is 50-odd ms of host-paced launches, and one
+        # hiccup of a shared host halves its rate (seen: 1,702 against 3,816 its/s in two consecutive runs) — the MEDIAN window
+        # is reported there, all of them listed; the headline form (--case edl50) times its K steps once, as the contract says
+        windows = []
+        for _ in range(max(1, repeats)):
+            reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run.step(verbose=False)
+            torch.cuda.synchronize()
+            windows.append(time.perf_counter() - t0)
+        dt = sorted(windows)[len(windows) // 2]
         its = int(sum(run.newton_its))
         dev = run.sys.dev
         nf = dev.nf
@@ -264,7 +270,7 @@ def edl50_case(device_id, steps=100, warmup=3, cpu=True):
                "ms_per_step": 1e3 * dt / steps, "dtype": "f64",
                "config": {"workload": "1D MPNP_CO2ER_EDL, 1D_variable_50um_mesh_5990, K+, 0.1 M KHCO3, V=-1: the %d dry-run steps "
                                       "(Newton rtol=atol=1e-4, omega=1, max 50; linear solve = block cyclic reduction, direct)" % steps,
-                          "n_vertices": nv, "n_dofs": nd, "newton_iterations": its},
+                          "n_vertices": nv, "n_dofs": nd, "newton_iterations": its, "windows_seconds": windows},
                "roofline": {"bound": "hbm", "kernel": "1D direct solve, block cyclic reduction over %d levels: k_tri_extract, k_bcr_forward per level, k_bcr_tail "
                                                       "(the levels of up to 4 rows, the single row, and back: one wave), k_bcr_backward per level" % (levels - 1),
                             "algorithmic_bytes_per_solve": alg_bytes, "mean_solve_us": solve_us,
@@ -416,7 +422,7 @@ def main():
     out = make_output(a, run, run.sys.dev, prof, nv, world, dt, its, kry) if rank == 0 else None
     if rank == 0 and world == 1 and not a.no_edl50 and a.refine == 0:
         try:
-            out["edl50"] = edl50_case(local, cpu=not a.no_cpu_baseline)
+            out["edl50"] = edl50_case(local, cpu=not a.no_cpu_baseline, repeats=3)
         except Exception as e:  # noqa: BLE001
             out["edl50"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     import threading

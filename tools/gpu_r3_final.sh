@@ -5,7 +5,6 @@ set -x
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r3f_gputests.log 2>&1; echo rc=$?; tail -4 gpurun_out/r3f_gputests.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python bench.py --steps 50 --warmup 2 > gpurun_out/r3f_bench.json 2> gpurun_out/r3f_bench.err; echo bench rc=$?
 rm -rf gpurun_out/r3f_stats gpurun_out/r3f_pmc_fetch gpurun_out/r3f_pmc_write
 rocprofv3 --kernel-trace --stats -d gpurun_out/r3f_stats --output-format csv -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-edl50 > gpurun_out/r3f_bench_under_rocprof.json 2> gpurun_out/r3f_b2.err
 cp $(find gpurun_out/r3f_stats -name "*kernel_stats.csv") gpurun_out/r3f_bench_kernel_stats.csv
@@ -14,7 +13,11 @@ rocprofv3 --pmc WRITE_SIZE -d gpurun_out/r3f_pmc_write --output-format csv -- py
 python tools/pmc_summary.py gpurun_out/r3f_pmc_fetch > gpurun_out/r3f_pmc_fetch.json
 python tools/pmc_summary.py gpurun_out/r3f_pmc_write > gpurun_out/r3f_pmc_write.json
 rm -rf gpurun_out/r3f_stats gpurun_out/r3f_pmc_fetch gpurun_out/r3f_pmc_write
-timeout -k 10 300 python bench.py --refine 2 --steps 10 --warmup 1 --no-cpu-baseline --no-edl50 > gpurun_out/r3f_bench_refine2.json 2>> gpurun_out/r3f_bench.err
+# the traffic file of THIS build first (in the box's copy of the tree; tools/make_traffic_json.py is run again on the merged files
+# at home), then the bench line that carries it
+python tools/make_traffic_json.py gpurun_out/r3f_pmc_fetch.json gpurun_out/r3f_pmc_write.json r03
+timeout -k 10 400 python bench.py --steps 50 --warmup 2 > gpurun_out/r3f_bench.json 2> gpurun_out/r3f_bench.err; echo bench rc=$?
+timeout -k 10 300 python bench.py --refine 2 --no-multilevel --steps 10 --warmup 1 --no-cpu-baseline --no-edl50 > gpurun_out/r3f_bench_refine2.json 2>> gpurun_out/r3f_bench.err
 timeout -k 10 300 python bench.py --refine 2 --multilevel --steps 10 --warmup 1 --no-cpu-baseline --no-edl50 > gpurun_out/r3f_bench_refine2_ml.json 2>> gpurun_out/r3f_bench.err
 timeout -k 10 400 python bench.py --refine 3 --multilevel --steps 3 --warmup 1 --no-cpu-baseline --no-edl50 > gpurun_out/r3f_bench_refine3_ml.json 2>> gpurun_out/r3f_bench.err
 timeout -k 10 200 python bench.py --case edl50 > gpurun_out/r3f_bench_edl50.json 2>> gpurun_out/r3f_bench.err
