@@ -46,7 +46,7 @@ if __name__ == "__main__":
     L, R = (float(sys.argv[1]), float(sys.argv[2])) if len(sys.argv) > 2 else (50.0, 5.0)
     tmp = tempfile.mkdtemp()
     res = {}
-    for world in (2, 4):
+    for world in [int(w) for w in os.environ.get("XCH_WORLDS", "2,4").split(",")]:   # (a GPU box admits 6 processes on its card)
         for form in (1, 0):
             out = os.path.join(tmp, "w%d_f%d.npz" % (world, form))
             mp.spawn(worker, args=(world, 29800 + 7 * world + form, out, form, L, R), nprocs=world, join=True)
