@@ -466,10 +466,13 @@ def main():
         # that delivers a stale ghost row does not get to report a rate.  The first one that passes is the headline;
         # GMPNP_BENCH_ALL_TRANSPORTS=1 times both device transports and reports the faster one.
         errors, tried = [], []
-        order = ["peer"] + (["rccl"] if backend == "nccl" else []) + ["host"]
+        # "peer" = the mailboxes with the exchange of a half-iteration riding inside the next launch as flagged words (round 3; like
+        # everything about this transport it has only ever run between processes on ONE card), "peer-separate" = the same mailboxes with
+        # the flag-based exchange launches of round 2: tried next if the first does not pass, before RCCL
+        order = ["peer", "peer-separate"] + (["rccl"] if backend == "nccl" else []) + ["host"]
         first_only = os.environ.get("GMPNP_BENCH_ALL_TRANSPORTS", "0") in ("", "0")
         if os.environ.get("GMPNP_BENCH_TRANSPORTS"):   # rehearsal / comparison runs: e.g. "host" or "rccl,host"
-            order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "rccl", "host")]
+            order = [x for x in os.environ["GMPNP_BENCH_TRANSPORTS"].split(",") if x in ("peer", "peer-separate", "rccl", "host")]
             first_only = True
 
         def agree(flag):
@@ -479,7 +482,9 @@ def main():
             return bool(int(t[0]))
 
         for transport in order:
-            if state["best"] is not None and (first_only or transport == "host"):
+            if state["best"] is not None and (first_only or transport == "host" or transport == "peer-separate"):
+                if transport == "peer-separate" and not first_only:
+                    continue      # (the comparison of GMPNP_BENCH_ALL_TRANSPORTS is between peer and RCCL)
                 break
             check = {"selftest": None, "run": None}
             state["checks"][transport] = check
@@ -488,8 +493,10 @@ def main():
                 state["phase"] = "%s: set-up" % transport
                 err = None
                 try:
-                    dk = {"device_id": local, "transport": transport, "shared_device": int(shared)}
-                    if transport == "peer" and os.environ.get("GMPNP_BENCH_EXCHANGE_FORM"):   # A/B runs: 1 = separate exchange launches
+                    dk = {"device_id": local, "transport": "peer" if transport == "peer-separate" else transport, "shared_device": int(shared)}
+                    if transport == "peer-separate":
+                        dk["exchange_form"] = 1
+                    elif transport == "peer" and os.environ.get("GMPNP_BENCH_EXCHANGE_FORM"):   # A/B runs: 1 = separate exchange launches
                         dk["exchange_form"] = int(os.environ["GMPNP_BENCH_EXCHANGE_FORM"])
                     prun = PoreRun(partition=(world, rank), device_kwargs=dk, **common)
                 except Exception as e:  # noqa: BLE001
@@ -519,7 +526,7 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 res = {"value": pits / float(tt[0]), "seconds": float(tt[0]), "newton_iterations": pits, "krylov_iterations": pkry,
                        "ms_per_step": 1e3 * float(tt[0]) / a.steps, "transport": transport, "state_vs_single_gpu": rel}
-                if transport == "peer":   # 2 = the exchange rides inside the next half-iteration's launch, 1 = separate launches
+                if transport in ("peer", "peer-separate"):   # 2 = the exchange rides inside the next half-iteration's launch, 1 = separate launches
                     res["exchange_form"] = prun.sys.ps.exchange_form()
                 check["run"] = "pass"
                 tried.append({"transport": transport, "value": res["value"], "krylov_iterations": pkry})
@@ -638,7 +645,9 @@ def attach_partitioned(out, a, world, part):
         out["config"] = dict(out["config"], newton_iterations=part["newton_iterations"], krylov_iterations=part["krylov_iterations"],
                              parallelism="ONE problem, %d z-slab mesh partitions, one per rank: ghost-row exchange + one fused all-reduce per "
                                          "BiCGStab half-iteration (%s), global coarse space (gmpnp_group_newton_solve)"
-                                         % (world, {"rccl": "RCCL on the solver's stream", "peer": "peer mailboxes: one kernel launch per collective, stores into the other ranks' IPC-mapped memory over xGMI"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
+                                         % (world, {"rccl": "RCCL on the solver's stream",
+                                                    "peer": "peer mailboxes: stores into the other ranks' IPC-mapped memory over xGMI; the exchange of a half-iteration rides inside the next launch as flagged words",
+                                                    "peer-separate": "peer mailboxes: stores into the other ranks' IPC-mapped memory over xGMI, one exchange launch per half-iteration"}.get(part.get("transport"), "host-staged transport over torch.distributed")))
         out["roofline"] = dict(out["roofline"], note="kernel durations sampled in the replica phase (same kernels, whole mesh per GPU)")
         out["partitioned"] = {k: part[k] for k in ("transport", "exchange_form", "seconds", "transports_timed", "earlier_errors", "note", "transport_checks",
                                                    "state_vs_single_gpu", "watchdog") if k in part}
