@@ -1047,7 +1047,7 @@ def test_bench_two_ranks_share_the_card_over_peer_mailboxes():
     assert out["value"] > 0 and out["replicas"]["value"] > 0
 
 
-def _library_partition_worker(rank, world, port, out_dir, transport="host", exchange_form=0):
+def _library_partition_worker(rank, world, port, out_dir, transport="host", exchange_form=0, refine=0):
     import sys
     from conftest import ROOT
     sys.path.insert(0, ROOT)
@@ -1062,8 +1062,8 @@ def _library_partition_worker(rank, world, port, out_dir, transport="host", exch
         from gmpnp_amd.problem import pore_problem
         pp = pore_parameters(concentration_elec=0.5, L=10e-9, R=5e-9)
         mesh = read_dolfin_xml(resolve_mesh_path(utilities_dir(), pp.mesh_name))
-        prob, _ = pore_problem(pp, mesh)
-        nv = mesh.num_vertices
+        prob, _ = pore_problem(pp, mesh, refine=refine)
+        nv = prob.coords.shape[0]
         kw = {"exchange_form": exchange_form} if transport == "peer" else {}
         with dist.PartitionedSolver(prob, world, rank=rank, transport=transport, **kw) as ps:
             form = ps.exchange_form()
@@ -1133,6 +1133,29 @@ def test_rccl_transport_at_world_size_one(pore10, gpu_lib):
         st = ps.newton_solve(gpu_lib.newton_options(MUMPS_09))
         u = ps.get_state()
     assert st["iterations"] == int(g["newton_its"][0]) and relerr(u, g["states"][0]) < 1e-8
+
+
+def test_peer_exchange_form_follows_the_residency_of_the_launch(gpu_lib, tmp_path):
+    """The exchange rides inside the next half-iteration's launch only where that launch — tiles, coarse workgroups AND exchange
+    workgroups — is resident at once (gmpnp_group_exchange_form = 2); a partition too large for that (here: the once-refined mesh,
+    1.8k tiles on 768 slots) runs the separate exchange launches (1), and so does everybody when asked to (exchange_form=1).  One rank
+    (the whole mesh as one partition), in a process of its own like the multi-rank tests: a process that loads this library BEFORE
+    PyTorch and initialises PyTorch's HIP runtime afterwards gets the four-launch form from the occupancy query (two HIP runtimes in
+    one process), which is the safe answer but not the one under test."""
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(GOLDEN, "pore10_steps.npz"))
+    states = {}
+    for k, (asked, runs, refine) in enumerate(((0, 2, 0), (1, 1, 0), (0, 1, 1))):
+        port = 29500 + (os.getpid() % 400) + 83 + k
+        mp.spawn(_library_partition_worker, args=(1, port, str(tmp_path), "peer", asked, refine), nprocs=1, join=True)
+        d = np.load(os.path.join(str(tmp_path), "libdist.npz"))
+        assert int(d["form"]) == runs
+        if refine == 0:
+            assert int(d["its"]) == int(g["newton_its"][0]) and relerr(d["u"], g["states"][0]) < 1e-8
+            states[runs] = d["u"]
+        else:
+            assert int(d["its"]) >= 5 and np.isfinite(d["u"]).all()
+    assert relerr(states[2], states[1]) < 1e-9
 
 
 def test_partition_plans_are_refused_when_inconsistent(pore10, gpu_lib):
