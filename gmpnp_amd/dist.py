@@ -186,6 +186,11 @@ class PartitionedSolver:
         exchange of a half-iteration rides inside the next launch where that launch is resident (2 launches per BiCGStab iteration),
         1 = separate exchange launches (4); every rank must pass the same value (gmpnp_group_set_exchange_form)."""
         from ctypes import byref, c_void_p, create_string_buffer
+        if rank is not None:
+            # one rank per process: torch.distributed carries the set-up (mailbox handles, communicator id, host-staged collectives).
+            # PyTorch first, THEN libgmpnp.so: the library then binds to the HIP runtime PyTorch ships instead of bringing the
+            # system's into the same process (README: two HIP runtimes on one GPU do not mix)
+            import torch  # noqa: F401
         from . import backend
         self.backend = backend
         self.lib = backend.load_library()
