@@ -55,13 +55,15 @@ def test_struct_layouts_match_the_header(backend, tmp_path):
 
 
 def test_no_cpu_fallback(backend, pore10):
-    """Without a GPU the product path must fail loudly; with one this test is a no-op."""
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("GPU present")
-    with pytest.raises(backend.GmpnpError) as ei:
-        backend.DeviceSolver(pore10[2])
-    assert ei.value.code == backend.ERR_HIP
+    """Without a GPU the product path must fail loudly; with one this test is a no-op.  (No PyTorch here: asking PyTorch whether a
+    GPU is there would initialise ITS HIP runtime on the card in a process whose libgmpnp.so is bound to the system's — README.)"""
+    try:
+        dev = backend.DeviceSolver(pore10[2])
+    except backend.GmpnpError as e:
+        assert e.code == backend.ERR_HIP and "no CPU fallback" in str(e)
+        return
+    dev.close()
+    pytest.skip("GPU present")
 
 
 def test_missing_library_is_an_error(backend, tmp_path):
